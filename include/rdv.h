@@ -1,0 +1,193 @@
+/*
+ * rdv.h — C ABI of the MI355X-native batched rendezvous environment (librdv_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path of cfdeinza/reinforcement-learning-rendezvous:
+ * RendezvousEnv.step()/reset() (reference rendezvous_env.py:160-270) and the helper methods the
+ * evaluators call after every step (get_observation :294, get_errors :451, check_collision :388,
+ * check_success :406, dist_from_koz :510).  The reference has no native plugin interface; its
+ * boundary is the Gym-0.21 Env API (rendezvous_env.py:10,133-144,160,223) wrapped into an SB3 VecEnv
+ * (main.py:33-34).  A Python host binds these entry points with ctypes and
+ * exposes them as an SB3-compatible VecEnv of N environments.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative RdvError; the message of the last failure on
+ *     the calling thread is returned by rdv_last_error().  Nothing throws across this ABI.
+ *   - all `float*`/`double*`/`uint8_t*`/`int32_t*` data arguments are DEVICE pointers owned by the
+ *     caller (e.g. torch tensors' data_ptr()) unless the name ends in `_host`.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream).  All work is enqueued
+ *     asynchronously on it; nothing here synchronises except rdv_get_stats/rdv_destroy.
+ *   - a handle is not thread-safe; different handles (device shards) may be used from different threads.
+ *   - rdv_step performs no allocation.
+ *   - quaternions are scalar-first (reference utils/quaternions.py:2).
+ */
+#ifndef RDV_H_
+#define RDV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDV_ABI_VERSION 1
+#define RDV_OBS_DIM 17    /* rendezvous_env.py:133-137 */
+#define RDV_ACT_DIM 6     /* rendezvous_env.py:140-144 */
+#define RDV_STATE_DIM 20  /* rc3 vc3 qc4 wc3 qt4 wt3, the column order of results/data_monte_carlo_initial_conditions.csv */
+#define RDV_DIAG_DIM 8    /* pos_err, vel_err, att_err, rot_err, in_koz(now), success(now), dist_from_koz, collided(latched) */
+
+typedef enum RdvError {
+  RDV_OK = 0,
+  RDV_ERR_INVALID_ARGUMENT = -1,
+  RDV_ERR_NO_DEVICE = -2,      /* no usable HIP device: the product path never falls back to the CPU */
+  RDV_ERR_HIP = -3,            /* a HIP runtime call failed; see rdv_last_error() */
+  RDV_ERR_OUT_OF_MEMORY = -4,
+  RDV_ERR_BAD_HANDLE = -5,
+  RDV_ERR_BAD_PARAMS = -6      /* violates an assert of the reference ctor (rendezvous_env.py:148-156) */
+} RdvError;
+
+/* Precision in which the persistent per-env state is held in HBM.  Arithmetic is fp64 in both. */
+typedef enum RdvStorage {
+  RDV_STORAGE_F32 = 0,  /* production: 20 floats + aux per env (the 293 B/env-step layout of SURVEY §8d) */
+  RDV_STORAGE_F64 = 1   /* parity mode: state held exactly as the reference holds it (NumPy float64) */
+} RdvStorage;
+
+/* What a finished episode does (SB3 DummyVecEnv auto-resets; monte_carlo.py:128 stops at done). */
+typedef enum RdvOnDone {
+  RDV_ON_DONE_RESET = 0,  /* in-kernel reset; obs returned is the first obs of the next episode */
+  RDV_ON_DONE_HALT = 1    /* env freezes: later steps leave it untouched and report done=1, reward=0 */
+} RdvOnDone;
+
+/*
+ * Environment parameters = the attributes RendezvousEnv.__init__ derives (rendezvous_env.py:52-126)
+ * plus the reward_kwargs of get_bubble_reward (:313).  All doubles, no padding, 58 of them.
+ * rdv_params_default() fills the reference defaults; the Python host re-derives dependent values
+ * (max_axial_distance, bubble_*, n) from user kwargs exactly as the reference ctor does.
+ */
+typedef struct RdvParams {
+  double nominal_rc0[3];        /* :52 */
+  double nominal_vc0[3];        /* :53 */
+  double nominal_qc0[4];        /* :54 */
+  double nominal_wc0[3];        /* :55 */
+  double nominal_qt0[4];        /* :56 */
+  double nominal_wt0[3];        /* :57 */
+  double rc0_range;             /* :60 [m]     */
+  double vc0_range;             /* :61 [m/s]   */
+  double qc0_range;             /* :62 [rad]   */
+  double wc0_range;             /* :63 [rad/s] */
+  double qt0_range;             /* :64 [rad]   */
+  double wt0_range;             /* :65 [rad/s] */
+  double dt;                    /* :69 */
+  double t_max;                 /* :70 */
+  double max_delta_v;           /* :81 */
+  double max_delta_w;           /* :82 */
+  double max_axial_distance;    /* :85 = |nominal_rc0| + 10 */
+  double max_axial_speed;       /* :86 */
+  double max_wc;                /* :87 */
+  double max_attitude_error;    /* :89 */
+  double koz_radius;            /* :93 */
+  double corridor_half_angle;   /* :94 */
+  double corridor_axis[3];      /* :95 target body frame */
+  double capture_axis[3];       /* :73 chaser body frame */
+  double rd[3];                 /* :104 target body frame */
+  double max_rd_error;          /* :105 */
+  double max_vd_error;          /* :106 */
+  double max_qd_error;          /* :107 */
+  double max_wd_error;          /* :108 */
+  double bubble_radius0;        /* :114 */
+  double bubble_decrease_rate;  /* :115 = 0.5*dt, per step */
+  double bubble_min;            /* :116 */
+  double n;                     /* :126 mean motion [rad/s] */
+  double collision_coef;        /* :313 */
+  double bonus_coef;            /* :313 */
+  double fuel_coef;             /* :313 */
+  double att_coef;              /* :313 */
+} RdvParams;
+
+/* Optional + required outputs of one step.  Nullable members are skipped when NULL. */
+typedef struct RdvStepOut {
+  float*   obs;             /* [N,17] required. After an auto-reset this is the reset observation (SB3 semantics) */
+  float*   reward;          /* [N]    required */
+  uint8_t* done;            /* [N]    required */
+  float*   terminal_obs;    /* [N,17] nullable; row i written only where done[i] (SB3 info["terminal_observation"]) */
+  float*   episode_return;  /* [N]    nullable; written where done (Monitor info["episode"]["r"]) */
+  int32_t* episode_length;  /* [N]    nullable; written where done (Monitor info["episode"]["l"]) */
+  uint8_t* done_reason;     /* [N]    nullable; 0 = not done, 1 obs, 2 time, 3 bubble, 4 attitude (rendezvous_env.py:377) */
+  double*  diag;            /* [N,8]  nullable; evaluator diagnostics of the post-step (pre-reset) state, RDV_DIAG_DIM */
+} RdvStepOut;
+
+/* Episode statistics accumulated on device with one wavefront reduction + one atomic per wave and step
+ * (the list logged by custom/custom_callbacks.py:285-298).  Counters are exact; sums are fp64 atomics. */
+typedef struct RdvStats {
+  uint64_t env_steps;          /* env transitions executed */
+  uint64_t episodes;           /* finished episodes */
+  uint64_t successes;          /* finished episodes with >= 1 success step */
+  uint64_t collisions;         /* finished episodes that entered the keep-out zone */
+  uint64_t reasons[4];         /* termination histogram: obs, time, bubble, attitude */
+  double   sum_return;         /* over finished episodes */
+  double   sum_length;         /* [steps] */
+  double   sum_delta_v;        /* [m/s] */
+  double   sum_delta_w;        /* [rad/s] */
+} RdvStats;
+
+typedef struct RdvEnvBatch* rdv_handle;
+
+int         rdv_version(void);
+const char* rdv_last_error(void);
+
+/* Reference ctor defaults (rendezvous_env.py:52-126, :313). Host-only, needs no GPU. */
+int rdv_params_default(RdvParams* out_host);
+/* The asserts of the reference ctor (:148-156) + positivity checks. Host-only. */
+int rdv_params_validate(const RdvParams* params_host);
+
+/* Bytes of device memory one batch needs (persistent SoA state + stats). Host-only. */
+int64_t rdv_workspace_bytes(int64_t n_envs, int storage);
+
+/*
+ * Create a batch of n_envs environments on `device`.  `env_id_offset` is the global index of local env 0
+ * (multi-GPU sharding: RNG streams are keyed by global env id, so results do not depend on the shard count).
+ * workspace: device memory of >= rdv_workspace_bytes() bytes, 256-B aligned, or NULL to let the library hipMalloc.
+ * Envs are NOT initialised until rdv_reset (as RendezvousEnv: state is None until reset(), :44-49).
+ */
+int rdv_create(const RdvParams* params_host, int64_t n_envs, int device, int storage, int on_done,
+               uint64_t seed, uint64_t env_id_offset, void* workspace, rdv_handle* out);
+int rdv_destroy(rdv_handle h);
+
+/* Replace parameters (reward coefficients, ranges, limits ...) between steps.  n/dt changes re-derive the CW matrix. */
+int rdv_set_params(rdv_handle h, const RdvParams* params_host);
+int rdv_get_params(rdv_handle h, RdvParams* out_host);
+/* Re-key the reset RNG (VecEnv.seed()).  Episode counters restart at 0. */
+int rdv_seed(rdv_handle h, uint64_t seed);
+
+/*
+ * Optional reset tape for parity tests: tape[e % depth][i][0..19] (fp64, device) is the state env i starts
+ * its e-th episode from, replacing the Philox draws (the reference uses NumPy's global MT19937, which cannot
+ * be replayed on device).  depth = 0 / tape = NULL returns to RNG resets.  The tape must outlive its use.
+ */
+int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth);
+
+/* RendezvousEnv.reset() (:223-270) for every env, or for envs with mask[i] != 0.  obs_out [N,17] nullable. */
+int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream);
+
+/* RendezvousEnv.step() (:160-221) for every env: ONE kernel launch.  actions [N,6] f32 (not clipped, as :170). */
+int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out_host, void* stream);
+
+/* Direct state access as monte_carlo.py:107-112 does (flags/aux are deliberately left untouched).
+ * states are [N,20] fp64 row-major in CSV column order. */
+int rdv_set_state(rdv_handle h, const double* states, void* stream);
+int rdv_get_state(rdv_handle h, double* states_out, void* stream);
+/* aux_out [N,8] fp64: t, bubble_radius, collided, success, total_delta_v, total_delta_w, episode_return, episode_index */
+int rdv_get_aux(rdv_handle h, double* aux_out, void* stream);
+
+/* get_observation() (:294) and the evaluator helpers (:388-468, :510) on the current state. */
+int rdv_observe(rdv_handle h, float* obs_out, void* stream);
+int rdv_diagnose(rdv_handle h, double* diag_out, void* stream);
+
+/* Copy the device statistics to the host (synchronises `stream`); reset != 0 zeroes them afterwards. */
+int rdv_get_stats(rdv_handle h, RdvStats* out_host, int reset, void* stream);
+
+int64_t rdv_num_envs(rdv_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDV_H_ */

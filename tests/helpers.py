@@ -1,0 +1,43 @@
+"""Shared helpers of the test-suite (tests may use the oracle; the product never does)."""
+import json
+import os
+
+import numpy as np
+
+import oracle
+from reinforcement_learning_rendezvous_amd.params import make_params
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def params_from_note(note_json):
+    """env kwargs recorded by make_golden.py -> (EnvParams, OrcParams)."""
+    kw = json.loads(str(note_json))
+    for k in ("rc0", "vc0", "qc0", "wc0", "qt0", "wt0"):
+        if k in kw:
+            kw[k] = np.array(kw[k], dtype=np.float64)
+    p = make_params(**kw)
+    return p, to_oracle_params(p)
+
+
+def to_oracle_params(p):
+    return oracle.OrcParams().update(p.to_dict())
+
+
+def counter_actions(seed, step, n, lo=0):
+    """U(-1,1) float32 actions keyed by (seed, step, env id): reproducible on any host, any shard."""
+    ids = np.arange(lo, lo + n, dtype=np.uint64)
+    out = np.empty((n, 6), np.float32)
+    for j in range(6):
+        x = (ids * np.uint64(6) + np.uint64(j)) ^ (np.uint64(step) << np.uint64(32)) ^ (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15))
+        # splitmix64 finaliser
+        x = (x + np.uint64(0x9E3779B97F4A7C15))
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+        out[:, j] = ((x >> np.uint64(40)).astype(np.float64) * (2.0 / (1 << 24)) - 1.0).astype(np.float32)
+    return out
