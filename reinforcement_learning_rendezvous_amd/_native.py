@@ -1,0 +1,113 @@
+"""
+ctypes binding of librdv_hip.so — the C ABI declared in include/rdv.h.
+
+There is no CPU fallback: if the library is missing or no HIP device is usable, the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from .params import EnvParams
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librdv_hip.so")
+CSRC = os.path.join(_PKG, "csrc")
+
+STORAGE_F32, STORAGE_F64 = 0, 1
+ON_DONE_RESET, ON_DONE_HALT = 0, 1
+OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM = 17, 6, 20, 8, 8
+
+ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVICE", -3: "RDV_ERR_HIP",
+               -4: "RDV_ERR_OUT_OF_MEMORY", -5: "RDV_ERR_BAD_HANDLE", -6: "RDV_ERR_BAD_PARAMS"}
+
+# every symbol include/rdv.h declares (tests/test_abi.py checks the list against the header and the .so)
+SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
+           "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
+           "rdv_reset", "rdv_step", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_observe", "rdv_diagnose",
+           "rdv_get_stats", "rdv_num_envs"]
+
+
+class RdvError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__(f"{ERROR_NAMES.get(code, code)}: {message}")
+        self.code = code
+
+
+class StepOut(C.Structure):
+    """RdvStepOut"""
+    _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("terminal_obs", C.c_void_p),
+                ("episode_return", C.c_void_p), ("episode_length", C.c_void_p), ("done_reason", C.c_void_p),
+                ("diag", C.c_void_p)]
+
+
+class Stats(C.Structure):
+    """RdvStats"""
+    _fields_ = [("env_steps", C.c_uint64), ("episodes", C.c_uint64), ("successes", C.c_uint64),
+                ("collisions", C.c_uint64), ("reasons", C.c_uint64 * 4), ("sum_return", C.c_double),
+                ("sum_length", C.c_double), ("sum_delta_v", C.c_double), ("sum_delta_w", C.c_double)]
+
+    def to_dict(self):
+        return dict(env_steps=int(self.env_steps), episodes=int(self.episodes), successes=int(self.successes),
+                    collisions=int(self.collisions), reasons=[int(x) for x in self.reasons],
+                    sum_return=float(self.sum_return), sum_length=float(self.sum_length),
+                    sum_delta_v=float(self.sum_delta_v), sum_delta_w=float(self.sum_delta_w))
+
+
+def build(force=False, quiet=True):
+    """Compile csrc/rdv_hip.hip for gfx950 into librdv_hip.so (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC, f) for f in ("rdv_hip.hip", "rdv_device.h")] + \
+           [os.path.join(_PKG, "..", "include", "rdv.h")]
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+    subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load librdv_hip.so and declare the signatures of include/rdv.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RdvError(-2, f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the product has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, u64, i32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32
+    PP = C.POINTER(EnvParams)
+    sig = {
+        "rdv_version": (C.c_int, []),
+        "rdv_last_error": (C.c_char_p, []),
+        "rdv_params_default": (C.c_int, [PP]),
+        "rdv_params_validate": (C.c_int, [PP]),
+        "rdv_workspace_bytes": (i64, [i64, C.c_int]),
+        "rdv_create": (C.c_int, [PP, i64, C.c_int, C.c_int, C.c_int, u64, u64, vp, C.POINTER(vp)]),
+        "rdv_destroy": (C.c_int, [vp]),
+        "rdv_set_params": (C.c_int, [vp, PP]),
+        "rdv_get_params": (C.c_int, [vp, PP]),
+        "rdv_seed": (C.c_int, [vp, u64]),
+        "rdv_set_reset_tape": (C.c_int, [vp, vp, i32]),
+        "rdv_reset": (C.c_int, [vp, vp, vp, vp]),
+        "rdv_step": (C.c_int, [vp, vp, C.POINTER(StepOut), vp]),
+        "rdv_set_state": (C.c_int, [vp, vp, vp]),
+        "rdv_get_state": (C.c_int, [vp, vp, vp]),
+        "rdv_get_aux": (C.c_int, [vp, vp, vp]),
+        "rdv_observe": (C.c_int, [vp, vp, vp]),
+        "rdv_diagnose": (C.c_int, [vp, vp, vp]),
+        "rdv_get_stats": (C.c_int, [vp, C.POINTER(Stats), C.c_int, vp]),
+        "rdv_num_envs": (i64, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != 0:
+        raise RdvError(code, lib().rdv_last_error().decode("utf-8", "replace"))
+    return code

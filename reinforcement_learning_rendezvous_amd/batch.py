@@ -1,0 +1,170 @@
+"""
+RendezvousBatch — N rendezvous environments resident on one MI355X, driven through the C ABI (include/rdv.h).
+
+Tensor-native: actions come in and observations/rewards/dones go out as torch tensors on the GPU; PyTorch is used
+for device memory and streams only.  The SB3-facing NumPy VecEnv lives in vec_env.py on top of this class.
+
+Reference semantics: RendezvousEnv.step()/reset() (rendezvous_env.py:160-270) for every env of the batch, with SB3
+DummyVecEnv auto-reset (``on_done="reset"``) or monte_carlo.py's stop-at-done (``on_done="halt"``).
+"""
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from .params import EnvParams, make_params
+
+_STORAGE = {"f32": N.STORAGE_F32, "f64": N.STORAGE_F64, N.STORAGE_F32: N.STORAGE_F32, N.STORAGE_F64: N.STORAGE_F64}
+_ON_DONE = {"reset": N.ON_DONE_RESET, "halt": N.ON_DONE_HALT}
+
+
+class RendezvousBatch:
+    def __init__(self, num_envs, params: EnvParams = None, device="cuda:0", storage="f32", on_done="reset", seed=0,
+                 env_id_offset=0, **env_kwargs):
+        """``env_kwargs`` are the keyword arguments of the reference constructor (rendezvous_env.py:17-37)."""
+        if params is not None and env_kwargs:
+            raise TypeError("pass either params or the reference constructor's keyword arguments, not both")
+        self.params = params.copy() if params is not None else make_params(**env_kwargs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise N.RdvError(-2, f"RendezvousBatch needs a GPU device, got {self.device} (there is no CPU path)")
+        if not torch.cuda.is_available():
+            raise N.RdvError(-2, "no HIP device visible to PyTorch (there is no CPU path)")
+        self.num_envs = int(num_envs)
+        self.storage = _STORAGE[storage]
+        self.on_done = _ON_DONE[on_done]
+        self._lib = N.lib()
+        self._h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", dev_index)
+        nbytes = self._lib.rdv_workspace_bytes(self.num_envs, self.storage)
+        if nbytes <= 0:
+            raise N.RdvError(-1, f"bad num_envs/storage: {num_envs}, {storage}")
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)   # caching allocator: 512-B aligned
+        N.check(self._lib.rdv_create(C.byref(self.params), self.num_envs, dev_index, self.storage, self.on_done,
+                                     C.c_uint64(seed), C.c_uint64(env_id_offset), self._ws.data_ptr(),
+                                     C.byref(self._h)))
+        n, dev = self.num_envs, self.device
+        self.obs = torch.zeros((n, N.OBS_DIM), dtype=torch.float32, device=dev)
+        self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.terminal_obs = torch.zeros((n, N.OBS_DIM), dtype=torch.float32, device=dev)
+        self.episode_return = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.episode_length = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.done_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.diag = None
+        self._tape = None
+        self._out = N.StepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                              self.terminal_obs.data_ptr(), self.episode_return.data_ptr(),
+                              self.episode_length.data_ptr(), self.done_reason.data_ptr(), None)
+        self._out_diag = None
+
+    # ------------------------------------------------------------------------------------------------ plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _check_tensor(self, t, shape, dtype, name):
+        if not (isinstance(t, torch.Tensor) and t.device == self.device and t.dtype == dtype
+                and tuple(t.shape) == tuple(shape) and t.is_contiguous()):
+            raise ValueError(f"{name}: expected contiguous {dtype} tensor of shape {tuple(shape)} on {self.device}, got "
+                             f"{getattr(t, 'dtype', type(t))} {tuple(getattr(t, 'shape', ()))} on {getattr(t, 'device', None)}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.rdv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------------ Gym surface
+    def reset(self, mask=None):
+        """RendezvousEnv.reset() (rendezvous_env.py:223-270) for all envs, or where ``mask`` (uint8/bool [N]) is set."""
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            self._check_tensor(mask, (self.num_envs,), torch.uint8, "mask")
+            mptr = mask.data_ptr()
+        if mask is None:
+            N.check(self._lib.rdv_reset(self._h, None, self.obs.data_ptr(), self._stream()))
+        else:
+            N.check(self._lib.rdv_reset(self._h, mptr, None, self._stream()))
+            N.check(self._lib.rdv_observe(self._h, self.obs.data_ptr(), self._stream()))
+        return self.obs
+
+    def step(self, actions, diag=False):
+        """RendezvousEnv.step() (rendezvous_env.py:160-221) for every env: one kernel launch.
+
+        Returns (obs, reward, done): views of buffers that the next step overwrites.  ``terminal_obs``,
+        ``episode_return``, ``episode_length`` (valid where done) and ``done_reason`` are attributes."""
+        self._check_tensor(actions, (self.num_envs, N.ACT_DIM), torch.float32, "actions")
+        out = self._out
+        if diag:
+            if self.diag is None:
+                self.diag = torch.zeros((self.num_envs, N.DIAG_DIM), dtype=torch.float64, device=self.device)
+                self._out_diag = N.StepOut(*[getattr(self._out, f) for f, _ in N.StepOut._fields_[:-1]],
+                                           self.diag.data_ptr())
+            out = self._out_diag
+        N.check(self._lib.rdv_step(self._h, actions.data_ptr(), C.byref(out), self._stream()))
+        return self.obs, self.reward, self.done
+
+    # ------------------------------------------------------------------------------------------------ evaluator helpers
+    def set_state(self, states):
+        """Overwrite rc, vc, qc, wc, qt, wt ([N,20] float64, CSV column order) as monte_carlo.py:107-112 does."""
+        states = states.to(device=self.device, dtype=torch.float64).contiguous()
+        self._check_tensor(states, (self.num_envs, N.STATE_DIM), torch.float64, "states")
+        N.check(self._lib.rdv_set_state(self._h, states.data_ptr(), self._stream()))
+
+    def _fetch(self, fn, width, dtype):
+        out = torch.empty((self.num_envs, width), dtype=dtype, device=self.device)
+        N.check(fn(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    def get_state(self):
+        return self._fetch(self._lib.rdv_get_state, N.STATE_DIM, torch.float64)
+
+    def get_aux(self):
+        """[N,8]: t, bubble_radius, collided, success, total_delta_v, total_delta_w, episode_return, episode_index"""
+        return self._fetch(self._lib.rdv_get_aux, N.AUX_DIM, torch.float64)
+
+    def observe(self):
+        """get_observation() (rendezvous_env.py:294)"""
+        return self._fetch(self._lib.rdv_observe, N.OBS_DIM, torch.float32)
+
+    def diagnose(self):
+        """[N,8]: get_errors() x4 (:451), check_collision() (:388), check_success() (:406), dist_from_koz() (:510), collided"""
+        return self._fetch(self._lib.rdv_diagnose, N.DIAG_DIM, torch.float64)
+
+    def get_stats(self, reset=False):
+        st = N.Stats()
+        N.check(self._lib.rdv_get_stats(self._h, C.byref(st), int(bool(reset)), self._stream()))
+        return st.to_dict()
+
+    # ------------------------------------------------------------------------------------------------ configuration
+    def seed(self, seed):
+        N.check(self._lib.rdv_seed(self._h, C.c_uint64(seed)))
+
+    def set_reset_tape(self, tape):
+        """tape: [depth, N, 20] float64 initial states replacing the RNG resets (parity tests); None to clear."""
+        if tape is None:
+            self._tape = None
+            N.check(self._lib.rdv_set_reset_tape(self._h, None, 0))
+            return
+        tape = tape.to(device=self.device, dtype=torch.float64).contiguous()
+        if tape.dim() != 3 or tuple(tape.shape[1:]) != (self.num_envs, N.STATE_DIM):
+            raise ValueError(f"tape: expected [depth, {self.num_envs}, 20], got {tuple(tape.shape)}")
+        self._tape = tape
+        N.check(self._lib.rdv_set_reset_tape(self._h, tape.data_ptr(), tape.shape[0]))
+
+    def set_params(self, params: EnvParams):
+        N.check(self._lib.rdv_set_params(self._h, C.byref(params)))
+        self.params = params.copy()
+
+    def set_reward_kwargs(self, **kw):
+        """The reference passes these to get_bubble_reward on every step (rendezvous_env.py:211, :313)."""
+        p = self.params.copy()
+        p.update(**kw)
+        self.set_params(p)

@@ -1,0 +1,618 @@
+// rdv_hip.hip — kernels + C ABI (include/rdv.h) of the MI355X-native batched rendezvous environment.
+//
+// Data layout in HBM (per batch of N envs, storage type ST = float | double):
+//   7 "chunk" arrays of N x (4 x ST): chunk c of env i at ws[(c*N + i)], i.e. struct-of-arrays at 16-byte (float4)
+//   granularity, so that every wave64 load/store instruction moves one contiguous 1 KiB (16 B per lane):
+//     c0 = rc.x rc.y rc.z vc.x      c1 = vc.y vc.z wc.x wc.y      c2 = wc.z bubble sum_dv sum_dw
+//     c3 = qc.w qc.x qc.y qc.z      c4 = qt.w qt.x qt.y qt.z      c5 = ep_return k flags episode (ints bit-cast)
+//     c6 = wt.x wt.y wt.z -         (read-only during a step: written by reset/set_state only)
+//   + one 128-byte statistics slot per wavefront (no same-address atomics: each wave owns its slot; the host sums them).
+// The boundary tensors keep the SB3 layout (actions [N,6], obs [N,17] row-major float32); each wave stages its
+// 64 rows through a wave-private LDS region so that the global accesses are contiguous 8/16-byte-per-lane.
+//
+// One launch per timestep: rdv_step -> step_kernel fuses impulse, CW propagation, both attitude updates, the
+// collision/success latches, observation, termination, reward, episode statistics and the in-kernel auto-reset.
+#include "rdv_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/rdv.h"
+
+namespace rdv {
+
+constexpr int kBlock = 256;             // 4 waves per workgroup
+constexpr int kWave = 64;
+constexpr int kChunks = 7;
+constexpr int kStatWords = 16;          // 128-byte slot per wave
+enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
+       ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
+
+template <typename ST> struct Vec4;
+template <> struct Vec4<float> { using type = float4; };
+template <> struct Vec4<double> { using type = double4; };
+
+__device__ __forceinline__ float u2s(uint32_t u, float) { return __uint_as_float(u); }
+__device__ __forceinline__ double u2s(uint32_t u, double) { return __longlong_as_double((long long)u); }
+__device__ __forceinline__ uint32_t s2u(float s) { return __float_as_uint(s); }
+__device__ __forceinline__ uint32_t s2u(double s) { return (uint32_t)__double_as_longlong(s); }
+
+template <typename ST>
+__device__ __forceinline__ void load_env(const typename Vec4<ST>::type* __restrict__ ws, int64_t n, int64_t i, Env& e) {
+  using V = typename Vec4<ST>::type;
+  const V c0 = ws[0 * n + i], c1 = ws[1 * n + i], c2 = ws[2 * n + i], c3 = ws[3 * n + i], c4 = ws[4 * n + i],
+          c5 = ws[5 * n + i], c6 = ws[6 * n + i];
+  e.rc[0] = c0.x; e.rc[1] = c0.y; e.rc[2] = c0.z; e.vc[0] = c0.w;
+  e.vc[1] = c1.x; e.vc[2] = c1.y; e.wc[0] = c1.z; e.wc[1] = c1.w;
+  e.wc[2] = c2.x; e.bubble = c2.y; e.sum_dv = c2.z; e.sum_dw = c2.w;
+  e.qc[0] = c3.x; e.qc[1] = c3.y; e.qc[2] = c3.z; e.qc[3] = c3.w;
+  e.qt[0] = c4.x; e.qt[1] = c4.y; e.qt[2] = c4.z; e.qt[3] = c4.w;
+  e.ep_ret = c5.x; e.k = (int32_t)s2u(c5.y); e.flags = s2u(c5.z); e.episode = s2u(c5.w);
+  e.wt[0] = c6.x; e.wt[1] = c6.y; e.wt[2] = c6.z;
+}
+
+template <typename ST>
+__device__ __forceinline__ void store_env(typename Vec4<ST>::type* __restrict__ ws, int64_t n, int64_t i, const Env& e, bool with_wt) {
+  using V = typename Vec4<ST>::type;
+  const ST t = ST(0);
+  V c;
+  c.x = (ST)e.rc[0]; c.y = (ST)e.rc[1]; c.z = (ST)e.rc[2]; c.w = (ST)e.vc[0]; ws[0 * n + i] = c;
+  c.x = (ST)e.vc[1]; c.y = (ST)e.vc[2]; c.z = (ST)e.wc[0]; c.w = (ST)e.wc[1]; ws[1 * n + i] = c;
+  c.x = (ST)e.wc[2]; c.y = (ST)e.bubble; c.z = (ST)e.sum_dv; c.w = (ST)e.sum_dw; ws[2 * n + i] = c;
+  c.x = (ST)e.qc[0]; c.y = (ST)e.qc[1]; c.z = (ST)e.qc[2]; c.w = (ST)e.qc[3]; ws[3 * n + i] = c;
+  c.x = (ST)e.qt[0]; c.y = (ST)e.qt[1]; c.z = (ST)e.qt[2]; c.w = (ST)e.qt[3]; ws[4 * n + i] = c;
+  c.x = (ST)e.ep_ret; c.y = u2s((uint32_t)e.k, t); c.z = u2s(e.flags, t); c.w = u2s(e.episode, t); ws[5 * n + i] = c;
+  if (with_wt) { c.x = (ST)e.wt[0]; c.y = (ST)e.wt[1]; c.z = (ST)e.wt[2]; c.w = ST(0); ws[6 * n + i] = c; }
+}
+
+// wave64 butterfly sums (ds_bpermute/DPP); every lane ends with the total, in a fixed order -> deterministic
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
+  return v;
+}
+
+struct StepArgs {
+  DevParams P;
+  void* ws;                 // chunk arrays
+  uint64_t* stats;          // [n_waves][16]
+  const float* actions;     // [N,6]
+  float* obs;               // [N,17]
+  float* reward;            // [N]
+  uint8_t* done;            // [N]
+  float* terminal_obs;      // nullable
+  float* episode_return;    // nullable
+  int32_t* episode_length;  // nullable
+  uint8_t* done_reason;     // nullable
+  double* diag;             // nullable [N,8]
+  const double* tape;       // nullable [depth][N][20]
+  int64_t n;
+  uint64_t seed;
+  uint64_t env_id_offset;
+  int32_t tape_depth;
+  int32_t on_done;
+};
+
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
+  using V = typename Vec4<ST>::type;
+  __shared__ __attribute__((aligned(16))) float lds[kBlock * RDV_OBS_DIM];   // 17,408 B: wave-private staging regions
+  const DevParams& P = A.P;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t wave_base = i - lane;
+  const int64_t n = A.n;
+  const bool active = i < n;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;    // valid envs of this wave (may be <= 0)
+  float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
+  V* ws = reinterpret_cast<V*>(A.ws);
+
+  // ---- state: 7 x 16-byte-per-lane loads, issued before anything depends on them
+  Env e;
+  if (active) load_env<ST>(ws, n, i, e);
+
+  // ---- actions [64,6] of this wave: 3 coalesced float2 loads per lane -> LDS -> own row
+  {
+    const float* src = A.actions + wave_base * RDV_ACT_DIM;
+    const int64_t valid = rows * RDV_ACT_DIM;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int idx = k * 128 + lane * 2;
+      if (idx + 1 < valid) {
+        const float2 v = *reinterpret_cast<const float2*>(src + idx);
+        *reinterpret_cast<float2*>(wl + idx) = v;
+      } else if (idx < valid) {
+        wl[idx] = src[idx];
+      }
+    }
+  }
+  __syncthreads();
+  float a[RDV_ACT_DIM];
+#pragma unroll
+  for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? wl[lane * RDV_ACT_DIM + j] : 0.0f;
+  __syncthreads();   // the region is reused for the observations below
+
+  StepResult r;
+  r.done = 0; r.reason = 0; r.reward = 0.0f;
+#pragma unroll
+  for (int j = 0; j < RDV_OBS_DIM; ++j) r.obs[j] = 0.0f;
+  bool stepped = false, did_reset = false;
+  if (active) {
+    if (e.flags & FLAG_HALTED) {
+      observation(P, e, r.obs);
+      r.done = 1;
+      if (A.diag) {
+        Derived d; double corr_l[3];
+        derive(P, e, d, corr_l);
+        diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);
+      }
+    } else {
+      Derived d; double corr_l[3];
+      step_env<ST>(P, e, a, r, d, corr_l);
+      stepped = true;
+      if (A.diag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);
+    }
+  }
+
+  // ---- episode statistics: wavefront reductions, then lanes 0..11 update this wave's private 128-byte slot
+  const bool fin = stepped && r.done;
+  const unsigned long long m_step = __ballot(stepped);
+  const unsigned long long m_fin = __ballot(fin);
+  if (m_step != 0ull) {   // wave-uniform
+    uint64_t* slot = A.stats + ((uint64_t)blockIdx.x * (kBlock / kWave) + wave_in_block) * kStatWords;
+    if (m_fin != 0ull) {
+      const unsigned long long m_succ = __ballot(fin && (e.flags >> SUCCESS_SHIFT) != 0u);
+      const unsigned long long m_coll = __ballot(fin && (e.flags & FLAG_COLLIDED));
+      const unsigned long long m_r1 = __ballot(fin && r.reason == 1), m_r2 = __ballot(fin && r.reason == 2);
+      const unsigned long long m_r3 = __ballot(fin && r.reason == 3), m_r4 = __ballot(fin && r.reason == 4);
+      const int s_len = wave_sum(fin ? e.k : 0);
+      const double s_ret = wave_sum(fin ? e.ep_ret : 0.0);
+      const double s_dv = wave_sum(fin ? e.sum_dv : 0.0);
+      const double s_dw = wave_sum(fin ? e.sum_dw : 0.0);
+      if (lane < 12) {
+        uint64_t iv = 0; double dv = 0.0;
+        switch (lane) {
+          case ST_STEPS: iv = __popcll(m_step); break;
+          case ST_EPISODES: iv = __popcll(m_fin); break;
+          case ST_SUCCESS: iv = __popcll(m_succ); break;
+          case ST_COLLIDED: iv = __popcll(m_coll); break;
+          case ST_REASON0: iv = __popcll(m_r1); break;
+          case ST_REASON1: iv = __popcll(m_r2); break;
+          case ST_REASON2: iv = __popcll(m_r3); break;
+          case ST_REASON3: iv = __popcll(m_r4); break;
+          case ST_SUM_LEN: iv = (uint64_t)s_len; break;
+          case ST_SUM_RET: dv = s_ret; break;
+          case ST_SUM_DV: dv = s_dv; break;
+          default: dv = s_dw; break;
+        }
+        if (lane <= ST_SUM_LEN) slot[lane] += iv;
+        else reinterpret_cast<double*>(slot)[lane] += dv;
+      }
+    } else if (lane == 0) {
+      slot[ST_STEPS] += __popcll(m_step);
+    }
+  }
+
+  // ---- per-env outputs of the transition
+  if (active) {
+    A.reward[i] = r.reward;
+    A.done[i] = (uint8_t)r.done;
+    if (A.done_reason) A.done_reason[i] = (uint8_t)r.reason;
+  }
+  if (fin) {
+    if (A.terminal_obs) {
+      float* t = A.terminal_obs + i * RDV_OBS_DIM;
+#pragma unroll
+      for (int j = 0; j < RDV_OBS_DIM; ++j) t[j] = r.obs[j];
+    }
+    if (A.episode_return) A.episode_return[i] = (float)e.ep_ret;
+    if (A.episode_length) A.episode_length[i] = e.k;
+    if (A.on_done == RDV_ON_DONE_RESET) {
+      // in-kernel auto-reset (SB3 DummyVecEnv semantics): the returned obs is the first obs of the next episode
+      const double* row = nullptr;
+      if (A.tape_depth > 0) row = A.tape + ((int64_t)(e.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
+      reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, row);
+      observation(P, e, r.obs);
+      did_reset = true;
+    } else if (A.on_done == RDV_ON_DONE_HALT) {
+      e.flags |= FLAG_HALTED;
+    }
+  }
+
+  // ---- observations: own row -> LDS (stride 17: conflict-free) -> contiguous 16-byte-per-lane stores
+#pragma unroll
+  for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
+  __syncthreads();
+  if (rows > 0) {
+    float* dst = A.obs + wave_base * RDV_OBS_DIM;
+    if (rows == kWave) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int q = k * kWave + lane;
+        *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
+      }
+      if (lane < 16) {
+        const int q = 4 * kWave + lane;
+        *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
+      }
+    } else {   // ragged tail wave
+      const int64_t valid = rows * RDV_OBS_DIM;
+      for (int j = 0; j < RDV_OBS_DIM; ++j) {
+        const int idx = j * kWave + lane;
+        if (idx < valid) dst[idx] = wl[idx];
+      }
+    }
+  }
+
+  // ---- state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt)
+  if (stepped) store_env<ST>(ws, n, i, e, did_reset);
+}
+
+// reset() for all envs or where mask != 0
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams P, void* ws_, int64_t n, const uint8_t* mask,
+                                                       float* obs, const double* tape, int32_t tape_depth, uint64_t seed,
+                                                       uint64_t env_id_offset, int fresh) {
+  using V = typename Vec4<ST>::type;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V* ws = reinterpret_cast<V*>(ws_);
+  if (mask && !mask[i]) return;
+  Env e;
+  load_env<ST>(ws, n, i, e);
+  if (fresh) e.episode = 0;   // first reset after create/seed: the workspace may hold anything
+  const double* row = nullptr;
+  if (tape_depth > 0) row = tape + ((int64_t)(e.episode % (uint32_t)tape_depth) * n + i) * RDV_STATE_DIM;
+  reset_env<ST>(P, e, seed, env_id_offset + (uint64_t)i, row);
+  store_env<ST>(ws, n, i, e, true);
+  if (obs) {
+    float o[RDV_OBS_DIM];
+    observation(P, e, o);
+    for (int j = 0; j < RDV_OBS_DIM; ++j) obs[i * RDV_OBS_DIM + j] = o[j];
+  }
+}
+
+enum { ACC_SET_STATE = 0, ACC_GET_STATE, ACC_GET_AUX, ACC_OBSERVE, ACC_DIAGNOSE };
+
+// state access / evaluator helpers (cold paths; one lane per env, row-major host-facing arrays)
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void* ws_, int64_t n, int what, const double* in,
+                                                        double* out, float* out_f32) {
+  using V = typename Vec4<ST>::type;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  V* ws = reinterpret_cast<V*>(ws_);
+  Env e;
+  load_env<ST>(ws, n, i, e);
+  const ST tag = ST(0);
+  if (what == ACC_SET_STATE) {          // monte_carlo.py:107-112: the 20 state reals only; flags and aux stay
+    const double* s = in + i * RDV_STATE_DIM;
+    for (int j = 0; j < 3; ++j) { e.rc[j] = canon(s[j], tag); e.vc[j] = canon(s[3 + j], tag); e.wc[j] = canon(s[10 + j], tag); e.wt[j] = canon(s[17 + j], tag); }
+    for (int j = 0; j < 4; ++j) { e.qc[j] = canon(s[6 + j], tag); e.qt[j] = canon(s[13 + j], tag); }
+    store_env<ST>(ws, n, i, e, true);
+  } else if (what == ACC_GET_STATE) {
+    double* s = out + i * RDV_STATE_DIM;
+    for (int j = 0; j < 3; ++j) { s[j] = e.rc[j]; s[3 + j] = e.vc[j]; s[10 + j] = e.wc[j]; s[17 + j] = e.wt[j]; }
+    for (int j = 0; j < 4; ++j) { s[6 + j] = e.qc[j]; s[13 + j] = e.qt[j]; }
+  } else if (what == ACC_GET_AUX) {
+    double* s = out + i * 8;
+    s[0] = rint((double)e.k * P.dt * 1e3) / 1e3; s[1] = e.bubble; s[2] = (e.flags & FLAG_COLLIDED) ? 1.0 : 0.0;
+    s[3] = (double)(e.flags >> SUCCESS_SHIFT); s[4] = e.sum_dv; s[5] = e.sum_dw; s[6] = e.ep_ret; s[7] = (double)e.episode;
+  } else if (what == ACC_OBSERVE) {
+    float o[RDV_OBS_DIM];
+    observation(P, e, o);
+    for (int j = 0; j < RDV_OBS_DIM; ++j) out_f32[i * RDV_OBS_DIM + j] = o[j];
+  } else {
+    Derived d; double corr_l[3];
+    derive(P, e, d, corr_l);
+    diagnostics(P, e, d, out + i * RDV_DIAG_DIM);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define RDV_HIP(call)                                                                                       \
+  do {                                                                                                      \
+    hipError_t err__ = (call);                                                                              \
+    if (err__ != hipSuccess) return fail(err__ == hipErrorOutOfMemory ? RDV_ERR_OUT_OF_MEMORY : RDV_ERR_HIP, \
+                                         "%s failed: %s", #call, hipGetErrorString(err__));                 \
+  } while (0)
+
+static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
+static inline int64_t n_waves(int64_t n) { return (n + kBlock - 1) / kBlock * (kBlock / kWave); }
+static inline int64_t chunk_bytes(int64_t n, int storage) { return align_up(kChunks * n * 4 * (storage == RDV_STORAGE_F64 ? 8 : 4), 256); }
+
+static void derive_params(const RdvParams& p, DevParams& d) {
+  std::memset(&d, 0, sizeof d);
+  const double n = p.n, t = p.dt, nt = n * t, c = std::cos(nt), s = std::sin(nt);
+  // dynamics.py:40-47, expression for expression
+  d.phi_xx = 4 - 3 * c;          d.phi_xvx = 1 / n * s;         d.phi_xvy = 2 / n * (1 - c);
+  d.phi_yx = 6 * (s - nt);       d.phi_yvx = -2 / n * (1 - c);  d.phi_yvy = 1 / n * (4 * s - 3 * nt);
+  d.phi_zz = c;                  d.phi_zvz = 1 / n * s;
+  d.phi_vxx = 3 * n * s;         d.phi_vxvx = c;                d.phi_vxvy = 2 * s;
+  d.phi_vyx = -6 * n * (1 - c);  d.phi_vyvx = -2 * s;           d.phi_vyvy = 4 * c - 3;
+  d.phi_vzz = -n * s;            d.phi_vzvz = c;
+  d.dt = p.dt; d.half_dt = 0.5 * p.dt; d.t_max = p.t_max;
+  d.max_delta_w = p.max_delta_w;
+  d.max_delta_v_f32 = (float)p.max_delta_v;
+  d.fuel_scale_f32 = (float)(p.dt * p.fuel_coef);
+  d.fuel_div_f32 = (float)(3 * p.max_delta_v);
+  d.obs_lo_r = -p.max_axial_distance; d.obs_span_r = p.max_axial_distance - (-p.max_axial_distance);
+  d.obs_lo_v = -p.max_axial_speed;    d.obs_span_v = p.max_axial_speed - (-p.max_axial_speed);
+  d.obs_lo_w = -p.max_wc;             d.obs_span_w = p.max_wc - (-p.max_wc);
+  d.max_attitude_error = p.max_attitude_error; d.koz_radius = p.koz_radius; d.corridor_half_angle = p.corridor_half_angle;
+  for (int i = 0; i < 3; ++i) { d.corridor_axis[i] = p.corridor_axis[i]; d.capture_axis[i] = p.capture_axis[i]; d.rd[i] = p.rd[i]; }
+  d.max_rd_error = p.max_rd_error; d.max_vd_error = p.max_vd_error; d.max_qd_error = p.max_qd_error; d.max_wd_error = p.max_wd_error;
+  d.bubble_radius0 = p.bubble_radius0; d.bubble_decrease_rate = p.bubble_decrease_rate; d.bubble_min = p.bubble_min;
+  d.att_term = p.dt * p.att_coef; d.coll_term = p.dt * p.collision_coef; d.bonus_term = p.dt * p.bonus_coef;
+  for (int i = 0; i < 3; ++i) { d.nominal_rc0[i] = p.nominal_rc0[i]; d.nominal_vc0[i] = p.nominal_vc0[i]; d.nominal_wc0[i] = p.nominal_wc0[i]; d.nominal_wt0[i] = p.nominal_wt0[i]; }
+  for (int i = 0; i < 4; ++i) { d.nominal_qc0[i] = p.nominal_qc0[i]; d.nominal_qt0[i] = p.nominal_qt0[i]; }
+  d.rc0_range = p.rc0_range; d.vc0_range = p.vc0_range; d.qc0_range = p.qc0_range;
+  d.wc0_range = p.wc0_range; d.qt0_range = p.qt0_range; d.wt0_range = p.wt0_range;
+}
+
+struct DeviceGuard {
+  int prev = -1; bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = (hipSetDevice(dev) == hipSuccess);
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
+}  // namespace rdv
+
+using namespace rdv;
+
+struct RdvEnvBatch {
+  uint32_t magic;
+  RdvParams params;
+  DevParams dev;
+  int64_t n;
+  int device, storage, on_done;
+  uint64_t seed, env_id_offset;
+  void* ws;          // chunks
+  uint64_t* stats;   // slots
+  bool own_ws;
+  bool fresh;        // no reset yet since create/seed
+  const double* tape;
+  int32_t tape_depth;
+  std::vector<uint64_t> host_slots;
+};
+static constexpr uint32_t kMagic = 0x52445631u;   // "RDV1"
+
+#define RDV_CHECK_HANDLE(h) \
+  if (!(h) || (h)->magic != kMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_handle")
+
+extern "C" {
+
+int rdv_version(void) { return RDV_ABI_VERSION; }
+const char* rdv_last_error(void) { return g_err; }
+
+int rdv_params_default(RdvParams* p) {
+  if (!p) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_params_default: null output");
+  std::memset(p, 0, sizeof *p);
+  const double rad = 3.14159265358979323846 / 180.0;
+  p->nominal_rc0[1] = -10.0; p->nominal_qc0[0] = 1.0; p->nominal_qt0[0] = 1.0;          // rendezvous_env.py:52-57
+  p->rc0_range = 1.0; p->vc0_range = 0.1; p->qc0_range = 1.0 * rad; p->wc0_range = 0.1 * rad;
+  p->qt0_range = 45.0 * rad; p->wt0_range = 3.0 * rad;                                   // :60-65
+  p->dt = 1.0; p->t_max = 120.0;                                                        // :69-70
+  const double mass = 100.0, inertia = 1.0 * 1.0 / 12.0 * mass * 2.0;                    // :74-79
+  p->max_delta_v = 10.0 / mass * 0.5; p->max_delta_w = 0.2 / inertia * 0.5;              // :81-82
+  p->max_axial_distance = 10.0 + 10.0; p->max_axial_speed = 5.0; p->max_wc = 10.0 * rad; // :85-87
+  p->max_attitude_error = 30.0 * rad;                                                    // :89
+  p->koz_radius = 5.0; p->corridor_half_angle = 30.0 * rad;                              // :93-94
+  p->corridor_axis[1] = -1.0; p->capture_axis[1] = 1.0; p->rd[1] = -2.0;                 // :95, :73, :104
+  p->max_rd_error = 0.5; p->max_vd_error = 0.1; p->max_qd_error = 5.0 * rad; p->max_wd_error = 1.0 * rad;   // :105-108
+  p->bubble_radius0 = p->max_axial_distance; p->bubble_decrease_rate = 0.5 * p->dt;      // :114-115
+  p->bubble_min = 2.0 + 2.0 * p->max_rd_error;                                           // :116
+  const double mu = 3.986004418e14, ro = 6371e3 + 800e3;                                 // :122-125
+  p->n = std::sqrt(mu / (ro * ro * ro));                                                 // :126
+  p->collision_coef = 0.5; p->bonus_coef = 8.0; p->fuel_coef = 0.2; p->att_coef = 1.0;   // :313
+  return RDV_OK;
+}
+
+int rdv_params_validate(const RdvParams* p) {
+  if (!p) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_params_validate: null params");
+  const double* d = reinterpret_cast<const double*>(p);
+  for (size_t i = 0; i < sizeof(RdvParams) / sizeof(double); ++i)
+    if (!std::isfinite(d[i])) return fail(RDV_ERR_BAD_PARAMS, "parameter #%zu is not finite", i);
+  const double rdn = std::sqrt(p->rd[0] * p->rd[0] + p->rd[1] * p->rd[1] + p->rd[2] * p->rd[2]);
+  if (!(rdn < p->koz_radius)) return fail(RDV_ERR_BAD_PARAMS, "Error: terminal position lies outside corridor.");        // :155
+  if (!(rdn - p->max_rd_error > 0)) return fail(RDV_ERR_BAD_PARAMS, "Error: position constraint allows collisions");   // :156
+  if (!(p->dt > 0) || !(p->n > 0) || !(p->max_axial_distance > 0) || !(p->max_axial_speed > 0) || !(p->max_wc > 0) ||
+      !(p->max_attitude_error > 0) || !(p->max_rd_error > 0) || !(p->max_qd_error > 0) || !(p->max_delta_v > 0))
+    return fail(RDV_ERR_BAD_PARAMS, "dt, n, the observation scales and the error limits must be positive");
+  return RDV_OK;
+}
+
+int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
+  if (n_envs <= 0 || (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64)) return -1;
+  return chunk_bytes(n_envs, storage) + n_waves(n_envs) * kStatWords * (int64_t)sizeof(uint64_t);
+}
+
+int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
+
+int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage, int on_done, uint64_t seed,
+               uint64_t env_id_offset, void* workspace, rdv_handle* out) {
+  if (!params || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: null params/out");
+  if (n_envs <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: n_envs must be positive (got %lld)", (long long)n_envs);
+  if (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: bad storage %d", storage);
+  if (on_done != RDV_ON_DONE_RESET && on_done != RDV_ON_DONE_HALT) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: bad on_done %d", on_done);
+  if (int rc = rdv_params_validate(params)) return rc;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+    return fail(RDV_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
+  if (device < 0 || device >= count) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: device %d out of range [0,%d)", device, count);
+  if (workspace && (reinterpret_cast<uintptr_t>(workspace) & 255)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: workspace must be 256-byte aligned");
+  DeviceGuard guard(device);
+  RdvEnvBatch* h = new (std::nothrow) RdvEnvBatch();
+  if (!h) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_create: host allocation failed");
+  h->magic = kMagic; h->params = *params; derive_params(*params, h->dev);
+  h->n = n_envs; h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
+  h->tape = nullptr; h->tape_depth = 0; h->fresh = true;
+  const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
+  if (workspace) { h->ws = workspace; h->own_ws = false; }
+  else {
+    hipError_t err = hipMalloc(&h->ws, (size_t)bytes);
+    if (err != hipSuccess) { delete h; return fail(RDV_ERR_OUT_OF_MEMORY, "hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(err)); }
+    h->own_ws = true;
+  }
+  h->stats = reinterpret_cast<uint64_t*>(static_cast<char*>(h->ws) + chunk_bytes(n_envs, storage));
+  hipError_t err = hipMemset(h->ws, 0, (size_t)bytes);
+  if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err)); }
+  h->host_slots.resize((size_t)(n_waves(n_envs) * kStatWords));
+  *out = h;
+  return RDV_OK;
+}
+
+int rdv_destroy(rdv_handle h) {
+  RDV_CHECK_HANDLE(h);
+  DeviceGuard guard(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->own_ws) (void)hipFree(h->ws);
+  h->magic = 0;
+  delete h;
+  return RDV_OK;
+}
+
+int rdv_set_params(rdv_handle h, const RdvParams* p) {
+  RDV_CHECK_HANDLE(h);
+  if (int rc = rdv_params_validate(p)) return rc;
+  h->params = *p; derive_params(*p, h->dev);
+  return RDV_OK;
+}
+int rdv_get_params(rdv_handle h, RdvParams* out) {
+  RDV_CHECK_HANDLE(h);
+  if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_params: null output");
+  *out = h->params;
+  return RDV_OK;
+}
+int rdv_seed(rdv_handle h, uint64_t seed) {
+  RDV_CHECK_HANDLE(h);
+  h->seed = seed; h->fresh = true;
+  return RDV_OK;
+}
+int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth) {
+  RDV_CHECK_HANDLE(h);
+  if ((tape == nullptr) != (depth <= 0)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_reset_tape: tape and depth must both be set or both be empty");
+  h->tape = tape; h->tape_depth = tape ? depth : 0;
+  return RDV_OK;
+}
+
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int fresh = (h->fresh && !mask) ? 1 : 0;
+  if (h->fresh && mask) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_reset: the first reset after create/seed must cover all envs (mask = NULL)");
+  if (h->storage == RDV_STORAGE_F32)
+    hipLaunchKernelGGL(reset_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
+  else
+    hipLaunchKernelGGL(reset_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
+  RDV_HIP(hipGetLastError());
+  h->fresh = false;
+  return RDV_OK;
+}
+
+int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!actions || !out || !out->obs || !out->reward || !out->done)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: actions, obs, reward and done are required");
+  if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: call rdv_reset first (state is undefined until reset(), as in the reference)");
+  if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: actions and obs must be 16-byte aligned");
+  if (out->diag && (reinterpret_cast<uintptr_t>(out->diag) & 7)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: diag must be 8-byte aligned");
+  DeviceGuard guard(h->device);
+  StepArgs A;
+  A.P = h->dev; A.ws = h->ws; A.stats = h->stats; A.actions = actions;
+  A.obs = out->obs; A.reward = out->reward; A.done = out->done; A.terminal_obs = out->terminal_obs;
+  A.episode_return = out->episode_return; A.episode_length = out->episode_length; A.done_reason = out->done_reason;
+  A.diag = out->diag; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
+  A.tape_depth = h->tape_depth; A.on_done = h->on_done;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(step_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, A);
+  else hipLaunchKernelGGL(step_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, A);
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
+}
+
+static int access(rdv_handle h, int what, const double* in, double* out, float* out_f32, void* stream) {
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(access_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
+  else hipLaunchKernelGGL(access_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
+}
+
+int rdv_set_state(rdv_handle h, const double* states, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!states) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_state: null states");
+  if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_state: call rdv_reset first (monte_carlo.py:106 resets before overwriting the state)");
+  return access(h, ACC_SET_STATE, states, nullptr, nullptr, stream);
+}
+int rdv_get_state(rdv_handle h, double* out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_state: null output");
+  return access(h, ACC_GET_STATE, nullptr, out, nullptr, stream);
+}
+int rdv_get_aux(rdv_handle h, double* out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_aux: null output");
+  return access(h, ACC_GET_AUX, nullptr, out, nullptr, stream);
+}
+int rdv_observe(rdv_handle h, float* out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_observe: null output");
+  return access(h, ACC_OBSERVE, nullptr, nullptr, out, stream);
+}
+int rdv_diagnose(rdv_handle h, double* out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_diagnose: null output");
+  return access(h, ACC_DIAGNOSE, nullptr, out, nullptr, stream);
+}
+
+int rdv_get_stats(rdv_handle h, RdvStats* out, int reset, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_stats: null output");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t bytes = h->host_slots.size() * sizeof(uint64_t);
+  RDV_HIP(hipMemcpyAsync(h->host_slots.data(), h->stats, bytes, hipMemcpyDeviceToHost, s));
+  if (reset) RDV_HIP(hipMemsetAsync(h->stats, 0, bytes, s));
+  RDV_HIP(hipStreamSynchronize(s));
+  std::memset(out, 0, sizeof *out);
+  const size_t waves = h->host_slots.size() / kStatWords;
+  for (size_t w = 0; w < waves; ++w) {   // fixed order: the sums are reproducible run to run
+    const uint64_t* sl = h->host_slots.data() + w * kStatWords;
+    const double* sd = reinterpret_cast<const double*>(sl);
+    out->env_steps += sl[ST_STEPS]; out->episodes += sl[ST_EPISODES]; out->successes += sl[ST_SUCCESS]; out->collisions += sl[ST_COLLIDED];
+    for (int r = 0; r < 4; ++r) out->reasons[r] += sl[ST_REASON0 + r];
+    out->sum_length += (double)sl[ST_SUM_LEN]; out->sum_return += sd[ST_SUM_RET]; out->sum_delta_v += sd[ST_SUM_DV]; out->sum_delta_w += sd[ST_SUM_DW];
+  }
+  return RDV_OK;
+}
+
+}  // extern "C"
