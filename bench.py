@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""
+bench.py — env steps/sec of the fused rendezvous step on MI355X (BASELINE.json metric).
+
+    python bench.py                      # 1 GPU, 65,536 envs, defaults finish in < 2 min
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W      # one rank per GPU, envs sharded by index (weak scaling)
+
+A "step" is one pass of the hot path over one batch: ONE launch of the fused step kernel over the rank's 65,536 envs
+(rendezvous_env.py:160-221 + auto-reset :223-270), with the float32 action batch already resident in HBM
+(16 pre-generated U(-1,1) batches used round-robin).  W untimed warm-up steps, then exactly K timed steps between
+barrier + synchronize on both sides; the MAX over ranks is used.  The K launches are replayed from HIP graphs
+(captured after the warm-up) so that the stream, not the Python interpreter, paces them; --no-graph times eager calls.
+
+One JSON line is printed by rank 0.  Besides the contract keys it carries
+  roofline     : HBM roofline of the step kernel.  achieved = 293 B (SURVEY §8d algorithmic bytes per env-step, fp32
+                 storage) x envs per launch / the launch-to-launch period measured with HIP events over the timed
+                 region on the launch stream; peak = 8 TB/s; traffic = PMC-measured bytes per launch (profiles/).
+  cpu_baseline : the CPU oracle (kind "port", oracle/rdv_oracle.c, same arithmetic) timed on this host's cores on a
+                 bounded sample of the same workload (rank 0, N=1 only).
+  policy_rollout: informational — the same envs driven by the 17-64-64-6 tanh MLP policy (BASELINE config 3:
+                 forward + Gaussian sample + clip in PyTorch-ROCm, then the step kernel), N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_ENV_STEP = 293      # read 32 words, write 41 words + 1 byte, fp32 storage
+HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+RING = 16                          # distinct action batches resident in HBM
+GRAPH_STEPS = 512                  # launches per captured graph (multiple of RING)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4096)
+    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--envs-per-gpu", type=int, default=65536)
+    ap.add_argument("--storage", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--no-graph", action="store_true", help="time eager ctypes launches instead of HIP-graph replays")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of the all-core CPU sample")
+    ap.add_argument("--no-policy", action="store_true", help="skip the informational MLP-policy rollout leg")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip timing the RCCL gather of rollouts to rank 0")
+    return ap.parse_args()
+
+
+def cpu_baseline(n, seconds):
+    """Times the CPU oracle (the checker, kind 'port') on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle
+    from tests.helpers import counter_actions
+    cores = len(os.sched_getaffinity(0))
+    acts = [counter_actions(1, t, n) for t in range(RING)]
+
+    def run(n_envs, threads, budget, min_steps):
+        orc = oracle.OracleBatch(n_envs, storage=oracle.STORAGE_F32, seed=0, n_threads=threads)
+        orc.reset()
+        a = [x[:n_envs] for x in acts]
+        orc.step(a[0])
+        t0 = time.perf_counter(); k = 0
+        while k < min_steps or time.perf_counter() - t0 < budget:
+            orc.step(a[k % RING]); k += 1
+        dt = time.perf_counter() - t0
+        return n_envs * k / dt, k, dt
+
+    v1, k1, d1 = run(4096, 1, min(3.0, seconds), 3)
+    vall, kall, dall = run(n, cores, seconds, 3)
+    return {"value": vall, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {kall} steps, random actions, auto-reset, OpenMP over envs ({dall:.1f} s)",
+            "single_core_value": v1, "single_core_sample": f"4096 envs x {k1} steps ({d1:.1f} s)"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
+        args.gpus = world
+    import torch
+    import torch.distributed as dist
+    from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    n, K, W = args.envs_per_gpu, args.steps, args.warmup
+    env = RendezvousBatch(n, device=device, storage=args.storage, seed=0, env_id_offset=rank * n)
+    gen = torch.Generator(device=device).manual_seed(1234 + rank)
+    ring = [(torch.rand((n, 6), device=device, generator=gen) * 2 - 1).contiguous() for _ in range(RING)]
+    env.reset()
+    for t in range(W):
+        env.step(ring[t % RING])
+    torch.cuda.synchronize()
+
+    # ---- capture: one graph of GRAPH_STEPS launches (+ one for the remainder) so the stream paces the timed region
+    use_graph = not args.no_graph
+    n_full, n_rem = K // GRAPH_STEPS, K % GRAPH_STEPS
+    g_full = g_rem = None
+
+    def capture(count):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for t in range(count):
+                env.step(ring[t % RING])
+        return g
+
+    if use_graph:
+        try:
+            g_full = capture(GRAPH_STEPS) if n_full else None
+            g_rem = capture(n_rem) if n_rem else None
+            torch.cuda.synchronize()
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            print(f"[bench] graph capture failed ({exc!r}); timing eager launches", file=sys.stderr)
+            use_graph = False
+
+    def run_timed():
+        if use_graph:
+            for _ in range(n_full):
+                g_full.replay()
+            if n_rem:
+                g_rem.replay()
+        else:
+            for t in range(K):
+                env.step(ring[t % RING])
+
+    stats0 = env.get_stats(reset=True)
+    del stats0
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ev0.record()
+    run_timed()
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    launch_us = ev0.elapsed_time(ev1) * 1e3 / K
+    stats = env.get_stats()
+    assert stats["env_steps"] == n * K, (stats["env_steps"], n * K)   # exactly K launches over n envs were executed
+
+    # ---- N>1: RCCL gather of one step's rollout (obs, reward, done) to rank 0, timed separately
+    gather_ms = None
+    if world > 1 and not args.no_gather:
+        bufs = None
+        if rank == 0:
+            bufs = [[torch.empty_like(x) for _ in range(world)] for x in (env.obs, env.reward, env.done)]
+        for it in range(25):
+            if it == 5:
+                torch.cuda.synchronize(); dist.barrier(); g0 = time.perf_counter()
+            for j, x in enumerate((env.obs, env.reward, env.done)):
+                dist.gather(x, bufs[j] if rank == 0 else None, dst=0)
+        torch.cuda.synchronize()
+        gather_ms = (time.perf_counter() - g0) / 20 * 1e3
+
+    out = None
+    if rank == 0:
+        total_steps = n * K * world
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (launch_us * 1e-6) / 1e9
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+            key = f"{args.storage}_{n}"
+            if key in pmc:
+                traffic = pmc[key]["bytes_per_launch"]
+        out = {
+            "metric": "env steps/sec", "value": total_steps / elapsed, "unit": "env steps/s", "n_gpus": world,
+            "steps": K, "warmup": W, "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"BASELINE config 4 per-GPU shard / config 3 env count: {n} envs per GPU, "
+                                   "U(-1,1) float32 actions resident in HBM, default env parameters, in-kernel auto-reset",
+                       "envs_per_gpu": n, "global_envs": n * world, "state_storage": args.storage,
+                       "launch": "hip-graph replay" if use_graph else "eager ctypes", "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "kernel": "rdv::step_kernel<float>" if
+                         args.storage == "f32" else "rdv::step_kernel<double>", "launch_us": launch_us,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n},
+            "episodes_finished": stats["episodes"],
+        }
+        if gather_ms is not None:
+            out["rccl_gather_to_rank0_ms"] = gather_ms
+
+    # ---- informational: MLP-policy rollout (config 3), N=1 only
+    if rank == 0 and world == 1 and not args.no_policy:
+        from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+        npz = os.path.join(ROOT, "tests", "golden", "mlp_policy.npz")
+        pol = (MlpPolicy.from_npz(npz) if os.path.exists(npz) else MlpPolicy()).to(device)
+        obs = env.reset()
+        k2 = 256
+        for _ in range(16):
+            obs, _, _ = env.step(pol.act(obs, deterministic=False))
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        for _ in range(k2):
+            obs, _, _ = env.step(pol.act(obs, deterministic=False))
+        torch.cuda.synchronize()
+        pdt = time.perf_counter() - p0
+        out["policy_rollout"] = {"value": n * k2 / pdt, "unit": "env steps/s", "steps": k2,
+                                 "policy": "MlpPolicy 17-64-64-6 tanh, stochastic, PyTorch-ROCm fp32 (eager)",
+                                 "weights": "tests/golden/mlp_policy.npz" if os.path.exists(npz) else "random init"}
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,11 +1,21 @@
 // rdv_device.h — per-lane device math of the fused rendezvous step for gfx950 (CDNA4, wave64).
 //
-// One lane owns one environment.  All arithmetic is fp64 (MI355X vector fp64 is half the fp32 rate and the path
-// needs < 2 kFLOP per env-step, so precision is free relative to the launch; it removes the fp32 hazards of
-// the 1e-5 rounding of the cosines in general.py:179 and the cancellation in the CW matrix).
-// The persistent state is held in HBM in the storage type ST (float in production, double in parity mode) and is
-// canonicalised to ST right after propagation, so that everything derived in the same step (flags, observation,
-// reward, diagnostics) is a function of exactly the stored state.
+// One lane owns one environment.  All arithmetic is fp64 (MI355X vector fp64 runs at half the fp32 rate and the path
+// needs ~1 kFLOP per env-step, so precision is free relative to the launch; it removes the fp32 hazards of SURVEY §7:
+// the 1e-5 rounding of the cosines in general.py:179 and the cancellation in the CW matrix).  The persistent state is
+// held in HBM in the storage type ST (float in production, double in parity mode) and is canonicalised to ST right
+// after propagation, so that everything derived in the same step (flags, observation, reward, diagnostics) is a
+// function of exactly the stored state.
+//
+// The kernel is latency-bound (one wave per SIMD at N = 65,536), so the instruction stream is kept short:
+//   - no fp64 division or sqrt on the step path: normalisations use v_rsq_f64 + 2 Newton steps, every constant divisor
+//     is a host-precomputed reciprocal;
+//   - the attitude update needs cos(t) and sin(t)/t only, both even in t: two 10-term polynomials in t^2 = (|w|dt/2)^2,
+//     no sqrt, no range reduction (|w|dt/2 <= pi/4 always holds inside the observation Box; a general path remains);
+//   - the rounded-cosine angle tests of general.py:179 (acos(round(c,5)) vs a fixed angle) are integer comparisons of
+//     k = rint(c*1e5) against thresholds the host derives with the same libm acos the oracle uses — exact, and no acos;
+//     acos is evaluated once per step, for the attitude term of the reward.
+// Results differ from the straight-line oracle by a few fp64 ulps (tests/test_gpu_parity.py states the tolerances).
 //
 // Citations are file:line in cfdeinza/reinforcement-learning-rendezvous.
 #pragma once
@@ -16,7 +26,7 @@
 namespace rdv {
 
 // ---------------------------------------------------------------------------------------------------------------
-// Kernel-argument parameter block (lives in SGPRs: it is wave-uniform).  Derived once on the host.
+// Parameter block, derived once on the host (derive_params in rdv_hip.hip), read through a uniform pointer (s_load).
 struct DevParams {
   // Clohessy-Wiltshire state-transition matrix for (n, dt), the 14 non-zeros of dynamics.py:40-47
   double phi_xx, phi_xvx, phi_xvy;      // row 0: 4-3c, s/n, 2(1-c)/n
@@ -25,21 +35,28 @@ struct DevParams {
   double phi_vxx, phi_vxvx, phi_vxvy;   // row 3: 3ns, c, 2s
   double phi_vyx, phi_vyvx, phi_vyvy;   // row 4: -6n(1-c), -2s, 4c-3
   double phi_vzz, phi_vzvz;             // row 5: -ns, c
-  double dt, half_dt, t_max;
+  double dt, half_dt;
   double max_delta_w;                   // np.float64 in the reference (:82) -> fp64 product (NEP 50)
   float  max_delta_v_f32;               // Python float * float32 array stays float32 (:172, :201)
   float  fuel_scale_f32;                // float32(dt * fuel_coef)  (:333)
   float  fuel_div_f32;                  // float32(3 * max_delta_v) (:333)
-  float  pad0;
-  double obs_lo_r, obs_span_r;          // -max_axial_distance, 2*max_axial_distance (normalize_value, general.py:243)
-  double obs_lo_v, obs_span_v;
-  double obs_lo_w, obs_span_w;
-  double max_attitude_error, koz_radius, corridor_half_angle;
+  int32_t k_time;                       // first step count k with round(k*dt, 3) >= t_max (:193, :368)
+  double obs_lo_r, obs_scale_r;         // normalize_value (general.py:243): (val - lo) * (2/(hi-lo)) - 1
+  double obs_lo_v, obs_scale_v;
+  double obs_lo_w, obs_scale_w;
+  double koz_radius, corridor_half_angle;
+  double inv_max_attitude_error, inv_max_rd_error, inv_max_qd_error;
   double corridor_axis[3], capture_axis[3], rd[3];
-  double max_rd_error, max_vd_error, max_qd_error, max_wd_error;
+  double inv_corridor_norm, inv_capture_norm;
+  double max_rd_error2, max_vd_error2, max_wd_error2;   // squared limits (:105-108)
+  // thresholds on k = rint(1e5*cos) equivalent to the reference's tests on acos(round(cos,5)) (general.py:179)
+  double kc_coll_max;                   // in corridor cone test (:401): angle > half_angle      <=> k <= kc_coll_max
+  double ka_done_max;                   // :370 attitude error > max_attitude_error               <=> k <= ka_done_max
+  double ka_succ_min;                   // :417 attitude error <= max_qd_error                    <=> k >= ka_succ_min
+  double ka_bonus_min;                  // :350 attitude error <  max_qd_error                    <=> k >= ka_bonus_min
   double bubble_radius0, bubble_decrease_rate, bubble_min;
   double att_term, coll_term, bonus_term;   // dt*att_coef, dt*collision_coef, dt*bonus_coef
-  // reset (rendezvous_env.py:229-258)
+  // reset (rendezvous_env.py:229-258); nominal quaternions pre-normalised (quat_product does it, quaternions.py:159-160)
   double nominal_rc0[3], nominal_vc0[3], nominal_qc0[4], nominal_wc0[3], nominal_qt0[4], nominal_wt0[3];
   double rc0_range, vc0_range, qc0_range, wc0_range, qt0_range, wt0_range;
 };
@@ -55,12 +72,11 @@ struct Env {
   uint32_t episode;
 };
 
-// Everything the flags / reward / done / diagnostics need from the (canonical) state.
+// What the flags / reward / done / diagnostics need from the (canonical) state.
 struct Derived {
-  double dist;       // |rc|
-  double att;        // get_attitude_error (:424-434)
-  double pos, vel, rot;   // get_errors (:451-468)
-  double corr_cos;   // cos of the angle between rc and the corridor axis in LVLH, before rounding
+  double dist;              // |rc|
+  double k_att, k_corr;     // rint(1e5 * cos) of the attitude error (:432) and of the corridor angle (:400)
+  double pos2, vel2, rot2;  // squared get_errors() entries (:463-466)
 };
 
 __device__ __forceinline__ double canon(double x, float) { return (double)(float)x; }
@@ -72,88 +88,136 @@ __device__ __forceinline__ float mul_f32_rn(float a, float b) {
   return a * b;
 }
 
-__device__ __forceinline__ double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-__device__ __forceinline__ double norm3(const double* a) { return sqrt(dot3(a, a)); }
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps (<= 2 ulp); replaces the sqrt-then-divide of every normalisation
+__device__ __forceinline__ double rsqrt64(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  const double hx = 0.5 * x;
+  y = y * fma(-hx * y, y, 1.5);
+  y = y * fma(-hx * y, y, 1.5);
+  return y;
+}
 
-// quaternions.py:48-68 (normalises q first, :57)
+__device__ __forceinline__ double dot3(const double* a, const double* b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+
+// cos(t) and sin(t)/t from u = t*t, for u <= kSmallU (t <= ~pi/4): Taylor to u^9, truncation < 2e-18
+constexpr double kSmallU = 0.62;
+__device__ __forceinline__ void cos_sinc_small(double u, double& c, double& sc) {
+  double p = -1.0 / 6402373705728000.0;            // -1/18!
+  p = fma(p, u, 1.0 / 20922789888000.0);           //  1/16!
+  p = fma(p, u, -1.0 / 87178291200.0);             // -1/14!
+  p = fma(p, u, 1.0 / 479001600.0);                //  1/12!
+  p = fma(p, u, -1.0 / 3628800.0);                 // -1/10!
+  p = fma(p, u, 1.0 / 40320.0);                    //  1/8!
+  p = fma(p, u, -1.0 / 720.0);                     // -1/6!
+  p = fma(p, u, 1.0 / 24.0);                       //  1/4!
+  p = fma(p, u, -0.5);
+  c = fma(p, u, 1.0);
+  double q = -1.0 / 121645100408832000.0;          // -1/19!
+  q = fma(q, u, 1.0 / 355687428096000.0);          //  1/17!
+  q = fma(q, u, -1.0 / 1307674368000.0);           // -1/15!
+  q = fma(q, u, 1.0 / 6227020800.0);               //  1/13!
+  q = fma(q, u, -1.0 / 39916800.0);                // -1/11!
+  q = fma(q, u, 1.0 / 362880.0);                   //  1/9!
+  q = fma(q, u, -1.0 / 5040.0);                    // -1/7!
+  q = fma(q, u, 1.0 / 120.0);                      //  1/5!
+  q = fma(q, u, -1.0 / 6.0);
+  sc = fma(q, u, 1.0);
+}
+// Larger angles (never reached inside the observation Box: |w| <= 10 deg/s): halve the angle until it is small,
+// then apply cos 2x = 2cos^2 x - 1, sinc 2x = sinc x cos x once per halving (error doubles per halving).
+__device__ __forceinline__ void cos_sinc(double u, double& c, double& sc) {
+  int halvings = 0;
+#pragma clang loop unroll(disable)
+  while (__builtin_expect(u > kSmallU && halvings < 64, 0)) { u *= 0.25; ++halvings; }
+  cos_sinc_small(u, c, sc);
+#pragma clang loop unroll(disable)
+  for (int h = 0; h < halvings; ++h) { sc = sc * c; c = fma(2.0 * c, c, -1.0); }
+}
+
+// R(q) of quaternions.py:48-68 (which normalises q first, :57)
 __device__ __forceinline__ void quat2mat(const double* q, double* m) {
-  const double mag = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  const double qw = q[0] / mag, qx = q[1] / mag, qy = q[2] / mag, qz = q[3] / mag;
-  m[0] = 2 * (qw * qw + qx * qx) - 1; m[1] = 2 * (qx * qy - qw * qz);     m[2] = 2 * (qx * qz + qw * qy);
-  m[3] = 2 * (qx * qy + qw * qz);     m[4] = 2 * (qw * qw + qy * qy) - 1; m[5] = 2 * (qy * qz - qw * qx);
-  m[6] = 2 * (qx * qz - qw * qy);     m[7] = 2 * (qy * qz + qw * qx);     m[8] = 2 * (qw * qw + qz * qz) - 1;
+  const double inv = rsqrt64(fma(q[3], q[3], fma(q[2], q[2], fma(q[1], q[1], q[0] * q[0]))));
+  const double qw = q[0] * inv, qx = q[1] * inv, qy = q[2] * inv, qz = q[3] * inv;
+  const double ww = qw * qw;
+  m[0] = fma(2.0, fma(qx, qx, ww), -1.0); m[1] = 2.0 * fma(qx, qy, -qw * qz);      m[2] = 2.0 * fma(qx, qz, qw * qy);
+  m[3] = 2.0 * fma(qx, qy, qw * qz);      m[4] = fma(2.0, fma(qy, qy, ww), -1.0);  m[5] = 2.0 * fma(qy, qz, -qw * qx);
+  m[6] = 2.0 * fma(qx, qz, -qw * qy);     m[7] = 2.0 * fma(qy, qz, qw * qx);       m[8] = fma(2.0, fma(qz, qz, ww), -1.0);
 }
 __device__ __forceinline__ void matvec(const double* m, const double* v, double* o) {
-  o[0] = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
-  o[1] = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
-  o[2] = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  o[0] = fma(m[2], v[2], fma(m[1], v[1], m[0] * v[0]));
+  o[1] = fma(m[5], v[2], fma(m[4], v[1], m[3] * v[0]));
+  o[2] = fma(m[8], v[2], fma(m[7], v[1], m[6] * v[0]));
 }
 __device__ __forceinline__ void matTvec(const double* m, const double* v, double* o) {
-  o[0] = m[0] * v[0] + m[3] * v[1] + m[6] * v[2];
-  o[1] = m[1] * v[0] + m[4] * v[1] + m[7] * v[2];
-  o[2] = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  o[0] = fma(m[6], v[2], fma(m[3], v[1], m[0] * v[0]));
+  o[1] = fma(m[7], v[2], fma(m[4], v[1], m[1] * v[0]));
+  o[2] = fma(m[8], v[2], fma(m[5], v[1], m[2] * v[0]));
 }
-
-// general.py:163-181: acos(round(cos, 5)); np.round == rint(x*1e5)/1e5 (ties to even)
-__device__ __forceinline__ double rounded_acos(double c) { return acos(rint(c * 1e5) / 1e5); }
 
 // rendezvous_env.py:552-604 with the reference's isotropic inertia and zero torque: w is constant and
 // q(t+dt) = normalize(q (x) [cos(|w|dt/2), w_hat sin(|w|dt/2)])  (body-frame rate: right multiplication, dynamics.py:137-151)
-__device__ __forceinline__ void integrate_attitude(double* q, const double* w, double half_dt, double dt) {
-  const double wn = norm3(w);
-  double s, c;
-  sincos(wn * half_dt, &s, &c);
-  const double k = wn > 0.0 ? s / wn : 0.5 * dt;
+__device__ __forceinline__ void integrate_attitude(double* q, const double* w, double half_dt) {
+  const double u = dot3(w, w) * (half_dt * half_dt);     // (|w| dt/2)^2
+  double c, sc;
+  cos_sinc(u, c, sc);
+  const double k = sc * half_dt;                          // sin(|w|dt/2)/|w|
   const double dx = w[0] * k, dy = w[1] * k, dz = w[2] * k;
   const double a = q[0], b = q[1], cc = q[2], d = q[3];
-  const double o0 = a * c - b * dx - cc * dy - d * dz;
-  const double o1 = a * dx + b * c + cc * dz - d * dy;
-  const double o2 = a * dy - b * dz + cc * c + d * dx;
-  const double o3 = a * dz + b * dy - cc * dx + d * c;
-  const double mag = sqrt(o0 * o0 + o1 * o1 + o2 * o2 + o3 * o3);   // :574, :601
-  q[0] = o0 / mag; q[1] = o1 / mag; q[2] = o2 / mag; q[3] = o3 / mag;
+  const double o0 = fma(a, c, -fma(b, dx, fma(cc, dy, d * dz)));
+  const double o1 = fma(a, dx, fma(b, c, fma(cc, dz, -d * dy)));
+  const double o2 = fma(a, dy, fma(cc, c, fma(d, dx, -b * dz)));
+  const double o3 = fma(a, dz, fma(b, dy, fma(d, c, -cc * dx)));
+  const double inv = rsqrt64(fma(o3, o3, fma(o2, o2, fma(o1, o1, o0 * o0))));   // :574, :601
+  q[0] = o0 * inv; q[1] = o1 * inv; q[2] = o2 * inv; q[3] = o3 * inv;
 }
 
 // Flags/reward inputs from the canonical state: one R(qc), one R(qt) per call (the reference rebuilds them ~10x per step).
-__device__ __forceinline__ void derive(const DevParams& P, const Env& e, Derived& d, double* corr_l /*R_t * corridor_axis*/) {
+__device__ __forceinline__ void derive(const DevParams& P, const Env& e, Derived& d) {
   double Rc[9], Rt[9];
   quat2mat(e.qc, Rc);
   quat2mat(e.qt, Rt);
-  double cap_l[3], wc_l[3], wt_l[3], rd_l[3];
+  double cap_l[3], wc_l[3], wt_l[3], rd_l[3], corr_l[3];
   matvec(Rc, P.capture_axis, cap_l);    // :431
   matvec(Rc, e.wc, wc_l);               // :458
   matvec(Rt, e.wt, wt_l);               // :459
   matvec(Rt, P.rd, rd_l);               // :460
   matvec(Rt, P.corridor_axis, corr_l);  // :400
-  const double vd_l[3] = {wt_l[1] * rd_l[2] - wt_l[2] * rd_l[1], wt_l[2] * rd_l[0] - wt_l[0] * rd_l[2],
-                          wt_l[0] * rd_l[1] - wt_l[1] * rd_l[0]};                       // :461
+  const double vd_l[3] = {fma(wt_l[1], rd_l[2], -wt_l[2] * rd_l[1]), fma(wt_l[2], rd_l[0], -wt_l[0] * rd_l[2]),
+                          fma(wt_l[0], rd_l[1], -wt_l[1] * rd_l[0])};                   // :461
   const double dp[3] = {e.rc[0] - rd_l[0], e.rc[1] - rd_l[1], e.rc[2] - rd_l[2]};
   const double dv[3] = {e.vc[0] - vd_l[0], e.vc[1] - vd_l[1], e.vc[2] - vd_l[2]};
   const double dw[3] = {wc_l[0] - wt_l[0], wc_l[1] - wt_l[1], wc_l[2] - wt_l[2]};
-  d.dist = norm3(e.rc);
-  d.pos = norm3(dp);                    // :463
-  d.vel = norm3(dv);                    // :464
-  d.rot = norm3(dw);                    // :466
-  const double nrc[3] = {-e.rc[0], -e.rc[1], -e.rc[2]};
-  d.att = rounded_acos(dot3(nrc, cap_l) / (d.dist * norm3(cap_l)));                     // :432
-  d.corr_cos = dot3(e.rc, corr_l) / (d.dist * norm3(corr_l));                           // general.py:179 before rounding
+  const double r2 = dot3(e.rc, e.rc);
+  const double inv_dist = rsqrt64(r2);
+  d.dist = r2 * inv_dist;
+  d.pos2 = dot3(dp, dp);                // :463
+  d.vel2 = dot3(dv, dv);                // :464
+  d.rot2 = dot3(dw, dw);                // :466
+  // general.py:179: round(cos, 5) == rint(cos*1e5)/1e5; rotations preserve |capture_axis|, |corridor_axis|
+  d.k_att = rint(-dot3(e.rc, cap_l) * (inv_dist * P.inv_capture_norm) * 1e5);           // :432
+  d.k_corr = rint(dot3(e.rc, corr_l) * (inv_dist * P.inv_corridor_norm) * 1e5);         // :400
 }
 
-// check_collision (:388-404): the rounded-cosine acos is only evaluated inside the KOZ sphere, as in the reference
+// k / 1e5 correctly rounded (k is an integer-valued double, |k| <= 1e5): product by 1e-5 plus one residual correction
+__device__ __forceinline__ double div_1e5(double k) {
+  const double q = k * 1e-5;
+  return fma(fma(-q, 1e5, k), 1e-5, q);
+}
+__device__ __forceinline__ double angle_of(double k) { return acos(div_1e5(k)); }     // general.py:179
+
+// check_collision (:388-404)
 __device__ __forceinline__ bool in_koz(const DevParams& P, const Derived& d) {
-  bool c = false;
-  if (d.dist < P.koz_radius) c = rounded_acos(d.corr_cos) > P.corridor_half_angle;
-  return c;
+  return d.dist < P.koz_radius && d.k_corr <= P.kc_coll_max;
+}
+// np.all(errors <= error_ranges) (:416-417)
+__device__ __forceinline__ bool errors_ok(const DevParams& P, const Derived& d) {
+  return d.pos2 <= P.max_rd_error2 && d.vel2 <= P.max_vd_error2 && d.k_att >= P.ka_succ_min && d.rot2 <= P.max_wd_error2;
 }
 
-__device__ __forceinline__ bool errors_ok(const DevParams& P, const Derived& d) {   // :416-417 (<=)
-  return d.pos <= P.max_rd_error && d.vel <= P.max_vd_error && d.att <= P.max_qd_error && d.rot <= P.max_wd_error;
-}
-
-// dist_from_koz (:510-537)
+// dist_from_koz (:510-537) — evaluator-only
 __device__ __forceinline__ double dist_from_koz(const DevParams& P, const Derived& d) {
   const double pos_mag = d.dist, r_koz = P.koz_radius, th_c = P.corridor_half_angle;
-  const double th = rounded_acos(d.corr_cos);
+  const double th = angle_of(d.k_corr);
   const double pi_2 = 1.57079632679489661923;
   double out;
   if (pos_mag < r_koz) {
@@ -179,13 +243,13 @@ __device__ __forceinline__ double dist_from_koz(const DevParams& P, const Derive
 // get_observation (:294-311) with normalize_value (general.py:243): (b-a)*(val-low)/(high-low)+a, a=-1, b=1
 __device__ __forceinline__ void observation(const DevParams& P, const Env& e, float* o) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[i] = (float)(2.0 * (e.rc[i] - P.obs_lo_r) / P.obs_span_r + -1.0);
+  for (int i = 0; i < 3; ++i) o[i] = (float)fma(e.rc[i] - P.obs_lo_r, P.obs_scale_r, -1.0);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[3 + i] = (float)(2.0 * (e.vc[i] - P.obs_lo_v) / P.obs_span_v + -1.0);
+  for (int i = 0; i < 3; ++i) o[3 + i] = (float)fma(e.vc[i] - P.obs_lo_v, P.obs_scale_v, -1.0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[6 + i] = (float)e.qc[i];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[10 + i] = (float)(2.0 * (e.wc[i] - P.obs_lo_w) / P.obs_span_w + -1.0);
+  for (int i = 0; i < 3; ++i) o[10 + i] = (float)fma(e.wc[i] - P.obs_lo_w, P.obs_scale_w, -1.0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[13 + i] = (float)e.qt[i];
 }
@@ -206,29 +270,24 @@ __device__ __forceinline__ double u01(uint32_t x) { return ((double)x + 0.5) * (
 
 // general.py:248-254: uniform(-1,1,3) normalised (cube-normalised direction, as the reference)
 __device__ __forceinline__ void unit_vector(double u0, double u1, double u2, double* o) {
-  const double v[3] = {-1.0 + 2.0 * u0, -1.0 + 2.0 * u1, -1.0 + 2.0 * u2};
-  const double n = norm3(v);
-  o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+  const double v[3] = {fma(2.0, u0, -1.0), fma(2.0, u1, -1.0), fma(2.0, u2, -1.0)};
+  const double inv = rsqrt64(dot3(v, v));
+  o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
 }
-// quaternions.py:11-27
-__device__ __forceinline__ void rot2quat(const double* axis_in, double theta, double* q) {
-  const double an = norm3(axis_in);
-  double s, c;
-  sincos(theta / 2, &s, &c);
-  q[0] = c; q[1] = axis_in[0] / an * s; q[2] = axis_in[1] / an * s; q[3] = axis_in[2] / an * s;
-  const double mag = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-  q[0] /= mag; q[1] /= mag; q[2] /= mag; q[3] /= mag;
-}
-// quaternions.py:149-170 (inputs normalised, output not)
-__device__ __forceinline__ void quat_product(const double* a_in, const double* b_in, double* o) {
-  const double ma = sqrt(a_in[0] * a_in[0] + a_in[1] * a_in[1] + a_in[2] * a_in[2] + a_in[3] * a_in[3]);
-  const double mb = sqrt(b_in[0] * b_in[0] + b_in[1] * b_in[1] + b_in[2] * b_in[2] + b_in[3] * b_in[3]);
-  const double a[4] = {a_in[0] / ma, a_in[1] / ma, a_in[2] / ma, a_in[3] / ma};
-  const double b[4] = {b_in[0] / mb, b_in[1] / mb, b_in[2] / mb, b_in[3] / mb};
-  o[0] = a[0] * b[0] - (a[1] * b[1] + a[2] * b[2] + a[3] * b[3]);
-  o[1] = a[0] * b[1] + b[0] * a[1] + (a[2] * b[3] - a[3] * b[2]);
-  o[2] = a[0] * b[2] + b[0] * a[2] + (a[3] * b[1] - a[1] * b[3]);
-  o[3] = a[0] * b[3] + b[0] * a[3] + (a[1] * b[2] - a[2] * b[1]);
+// quat_product(rot2quat(axis, theta), nominal) (:239/:255, quaternions.py:11-27, :149-170).  `axis` is a unit vector and
+// `nominal` is pre-normalised, so the reference's re-normalisations of axis, of the rotation quaternion and of both
+// factors are identities up to rounding and are dropped; as in the reference, the product itself is not normalised.
+__device__ __forceinline__ void deviate(const double* axis, double theta, const double* nominal, double* o) {
+  const double half = 0.5 * theta;
+  double c, sc;
+  cos_sinc(half * half, c, sc);
+  const double s = sc * half;
+  const double a[4] = {c, axis[0] * s, axis[1] * s, axis[2] * s};
+  const double* b = nominal;
+  o[0] = fma(a[0], b[0], -fma(a[1], b[1], fma(a[2], b[2], a[3] * b[3])));
+  o[1] = fma(a[0], b[1], fma(b[0], a[1], fma(a[2], b[3], -a[3] * b[2])));
+  o[2] = fma(a[0], b[2], fma(b[0], a[2], fma(a[3], b[1], -a[1] * b[3])));
+  o[3] = fma(a[0], b[3], fma(b[0], a[3], fma(a[1], b[2], -a[2] * b[1])));
 }
 
 // reset (:223-270).  Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
@@ -255,28 +314,30 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Env& e, uint64_t s
       philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
       u[4 * j + 0] = u01(c0); u[4 * j + 1] = u01(c1); u[4 * j + 2] = u01(c2); u[4 * j + 3] = u01(c3);
     }
-    double dir[3], qdev[4], tmp[3], R[9];
+    double dir[3], tmp[3], R[9];
     unit_vector(u[0], u[1], u[2], dir);                                   // :231
     { const double m = P.rc0_range * u[3];
-      for (int i = 0; i < 3; ++i) e.rc[i] = P.nominal_rc0[i] + dir[i] * m; }   // :253
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e.rc[i] = fma(dir[i], m, P.nominal_rc0[i]); }   // :253
     unit_vector(u[4], u[5], u[6], dir);                                   // :234
     { const double m = P.vc0_range * u[7];
-      for (int i = 0; i < 3; ++i) e.vc[i] = P.nominal_vc0[i] + dir[i] * m; }   // :254
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e.vc[i] = fma(dir[i], m, P.nominal_vc0[i]); }   // :254
     const double theta_c = P.qc0_range * u[8];                            // :237
     unit_vector(u[9], u[10], u[11], dir);                                 // :238
-    rot2quat(dir, theta_c, qdev);                                         // :239
-    quat_product(qdev, P.nominal_qc0, e.qc);                              // :255
+    deviate(dir, theta_c, P.nominal_qc0, e.qc);                           // :239, :255
     unit_vector(u[12], u[13], u[14], dir);                                // :242
     { const double m = P.wc0_range * u[15];
-      for (int i = 0; i < 3; ++i) tmp[i] = P.nominal_wc0[i] + dir[i] * m; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tmp[i] = fma(dir[i], m, P.nominal_wc0[i]); }
     quat2mat(e.qc, R); matTvec(R, tmp, e.wc);                             // :256 lvlh2chaser
     const double theta_t = P.qt0_range * u[16];                           // :245
     unit_vector(u[17], u[18], u[19], dir);                                // :246
-    rot2quat(dir, theta_t, qdev);                                         // :247
-    quat_product(qdev, P.nominal_qt0, e.qt);                              // :257
+    deviate(dir, theta_t, P.nominal_qt0, e.qt);                           // :247, :257
     unit_vector(u[20], u[21], u[22], dir);                                // :250
     { const double m = P.wt0_range * u[23];
-      for (int i = 0; i < 3; ++i) tmp[i] = P.nominal_wt0[i] + dir[i] * m; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) tmp[i] = fma(dir[i], m, P.nominal_wt0[i]); }
     quat2mat(e.qt, R); matTvec(R, tmp, e.wt);                             // :258 lvlh2target
   }
   const ST tag = ST(0);
@@ -284,8 +345,8 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Env& e, uint64_t s
   for (int i = 0; i < 3; ++i) { e.rc[i] = canon(e.rc[i], tag); e.vc[i] = canon(e.vc[i], tag); e.wc[i] = canon(e.wc[i], tag); e.wt[i] = canon(e.wt[i], tag); }
 #pragma unroll
   for (int i = 0; i < 4; ++i) { e.qc[i] = canon(e.qc[i], tag); e.qt[i] = canon(e.qt[i], tag); }
-  Derived d; double corr_l[3];
-  derive(P, e, d, corr_l);
+  Derived d;
+  derive(P, e, d);
   const bool coll = in_koz(P, d);                                         // :261
   const bool succ = !coll && errors_ok(P, d);                             // :262
   e.flags = (coll ? FLAG_COLLIDED : 0u) | ((succ ? 1u : 0u) << SUCCESS_SHIFT);
@@ -305,34 +366,35 @@ struct StepResult {
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
 template <typename ST>
-__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, double* corr_l) {
+__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d) {
   const ST tag = ST(0);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
   double Rc0[9];
   quat2mat(e.qc, Rc0);
-  const double dvb[3] = {(double)mul_f32_rn(a[0], P.max_delta_v_f32), (double)mul_f32_rn(a[1], P.max_delta_v_f32), (double)mul_f32_rn(a[2], P.max_delta_v_f32)};
+  const double dvb[3] = {(double)mul_f32_rn(a[0], P.max_delta_v_f32), (double)mul_f32_rn(a[1], P.max_delta_v_f32),
+                         (double)mul_f32_rn(a[2], P.max_delta_v_f32)};
   double dv_l[3];
   matvec(Rc0, dvb, dv_l);
   const double vx = e.vc[0] + dv_l[0], vy = e.vc[1] + dv_l[1], vz = e.vc[2] + dv_l[2];   // :176
   const double x = e.rc[0], y = e.rc[1], z = e.rc[2];
-  // :177 closed-form Clohessy-Wiltshire propagation (dynamics.py:40-51)
-  e.rc[0] = canon(P.phi_xx * x + P.phi_xvx * vx + P.phi_xvy * vy, tag);
-  e.rc[1] = canon(P.phi_yx * x + y + P.phi_yvx * vx + P.phi_yvy * vy, tag);
-  e.rc[2] = canon(P.phi_zz * z + P.phi_zvz * vz, tag);
-  e.vc[0] = canon(P.phi_vxx * x + P.phi_vxvx * vx + P.phi_vxvy * vy, tag);
-  e.vc[1] = canon(P.phi_vyx * x + P.phi_vyvx * vx + P.phi_vyvy * vy, tag);
-  e.vc[2] = canon(P.phi_vzz * z + P.phi_vzvz * vz, tag);
+  // :177 closed-form Clohessy-Wiltshire propagation (dynamics.py:40-51), summed in the reference's column order
+  e.rc[0] = canon(fma(P.phi_xvy, vy, fma(P.phi_xvx, vx, P.phi_xx * x)), tag);
+  e.rc[1] = canon(fma(P.phi_yvy, vy, fma(P.phi_yvx, vx, fma(P.phi_yx, x, y))), tag);
+  e.rc[2] = canon(fma(P.phi_zvz, vz, P.phi_zz * z), tag);
+  e.vc[0] = canon(fma(P.phi_vxvy, vy, fma(P.phi_vxvx, vx, P.phi_vxx * x)), tag);
+  e.vc[1] = canon(fma(P.phi_vyvy, vy, fma(P.phi_vyvx, vx, P.phi_vyx * x)), tag);
+  e.vc[2] = canon(fma(P.phi_vzvz, vz, P.phi_vzz * z), tag);
   // :173, :180 delta_w = a[3:] * max_delta_w is a float64 product (max_delta_w is np.float64)
 #pragma unroll
-  for (int i = 0; i < 3; ++i) e.wc[i] = e.wc[i] + (double)a[3 + i] * P.max_delta_w;
-  integrate_attitude(e.qc, e.wc, P.half_dt, P.dt);   // :181
-  integrate_attitude(e.qt, e.wt, P.half_dt, P.dt);   // :184
+  for (int i = 0; i < 3; ++i) e.wc[i] = fma((double)a[3 + i], P.max_delta_w, e.wc[i]);
+  integrate_attitude(e.qc, e.wc, P.half_dt);   // :181
+  integrate_attitude(e.qt, e.wt, P.half_dt);   // :184
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = canon(e.wc[i], tag);
 #pragma unroll
   for (int i = 0; i < 4; ++i) { e.qc[i] = canon(e.qc[i], tag); e.qt[i] = canon(e.qt[i], tag); }
 
-  derive(P, e, d, corr_l);
+  derive(P, e, d);
   const bool inst_coll = in_koz(P, d);
   // :187-190
   if (!(e.flags & FLAG_COLLIDED)) {
@@ -340,43 +402,38 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
     else if (errors_ok(P, d)) e.flags += (1u << SUCCESS_SHIFT);
   }
   e.k += 1;                                                           // :193 t = round(k*dt, 3)
-  const double t = rint((double)e.k * P.dt * 1e3) / 1e3;
-  double b = e.bubble - P.bubble_decrease_rate;                       // :196-198
-  if (b < P.bubble_min) b = P.bubble_min;
-  e.bubble = canon(b, tag);
+  e.bubble = canon(fmax(e.bubble - P.bubble_decrease_rate, P.bubble_min), tag);   // :196-198
   // :201-202; float32 sums, see the promotion table in oracle/rdv_oracle.c
   const float sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
   const float sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
   e.sum_dv = (double)((float)e.sum_dv + mul_f32_rn(sum_v, P.max_delta_v_f32));
-  e.sum_dw = canon(e.sum_dw + (double)sum_w * P.max_delta_w, tag);
+  e.sum_dw = canon(fma((double)sum_w, P.max_delta_w, e.sum_dw), tag);
 
   observation(P, e, r.obs);                                           // :205
   // :355-386
   bool outside = false;
 #pragma unroll
-  for (int i = 0; i < 17; ++i) outside |= !(r.obs[i] >= -1.0f && r.obs[i] <= 1.0f);   // Box.contains; NaN -> outside
-  const bool c_time = t >= P.t_max, c_bubble = d.dist > e.bubble, c_att = d.att > P.max_attitude_error;
+  for (int i = 0; i < 17; ++i) outside |= !(fabsf(r.obs[i]) <= 1.0f);                  // Box.contains; NaN -> outside
+  const bool c_time = e.k >= P.k_time, c_bubble = d.dist > e.bubble, c_att = d.k_att <= P.ka_done_max;
   r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
   r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
   // :313-353
-  double rew = P.att_term * (1 - d.att / P.max_attitude_error);                        // :329
-  rew += (double)(mul_f32_rn(P.fuel_scale_f32, sum_v) / P.fuel_div_f32);                        // :333
+  const double att = angle_of(d.k_att);
+  double rew = P.att_term * fma(-att, P.inv_max_attitude_error, 1.0);                  // :329
+  rew += (double)(mul_f32_rn(P.fuel_scale_f32, sum_v) / P.fuel_div_f32);               // :333
   if (inst_coll) rew -= P.coll_term;                                                   // :336-337
-  if (d.dist < P.koz_radius && !(e.flags & FLAG_COLLIDED)) {                           // :340
-    if (d.pos < P.max_rd_error) {                                                      // :348-351
-      rew += P.bonus_term * (2 - d.pos / P.max_rd_error);
-      if (d.att < P.max_qd_error) rew += P.bonus_term * (2 - d.att / P.max_qd_error);
-    }
+  if (d.dist < P.koz_radius && !(e.flags & FLAG_COLLIDED) && d.pos2 < P.max_rd_error2) {   // :340, :348
+    rew += P.bonus_term * fma(-sqrt(d.pos2), P.inv_max_rd_error, 2.0);                 // :349
+    if (d.k_att >= P.ka_bonus_min) rew += P.bonus_term * fma(-att, P.inv_max_qd_error, 2.0);   // :350-351
   }
   e.ep_ret = canon(e.ep_ret + rew, tag);
   r.reward = (float)rew;
 }
 
-// diagnostics row (RDV_DIAG_DIM = 8)
+// diagnostics row (RDV_DIAG_DIM = 8) — evaluator-only
 __device__ __forceinline__ void diagnostics(const DevParams& P, const Env& e, const Derived& d, double* out) {
-  const bool inst = in_koz(P, d);
-  out[0] = d.pos; out[1] = d.vel; out[2] = d.att; out[3] = d.rot;
-  out[4] = inst ? 1.0 : 0.0;
+  out[0] = sqrt(d.pos2); out[1] = sqrt(d.vel2); out[2] = angle_of(d.k_att); out[3] = sqrt(d.rot2);
+  out[4] = in_koz(P, d) ? 1.0 : 0.0;
   out[5] = (!(e.flags & FLAG_COLLIDED) && errors_ok(P, d)) ? 1.0 : 0.0;    // check_success (:406-422)
   out[6] = dist_from_koz(P, d);
   out[7] = (e.flags & FLAG_COLLIDED) ? 1.0 : 0.0;

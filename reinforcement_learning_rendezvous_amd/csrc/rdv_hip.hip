@@ -84,7 +84,7 @@ __device__ __forceinline__ int wave_sum(int v) {
 }
 
 struct StepArgs {
-  DevParams P;
+  const DevParams* __restrict__ P;   // device copy of the parameter block (uniform -> scalar loads)
   void* ws;                 // chunk arrays
   uint64_t* stats;          // [n_waves][16]
   const float* actions;     // [N,6]
@@ -104,11 +104,11 @@ struct StepArgs {
   int32_t on_done;
 };
 
-template <typename ST>
+template <typename ST, bool kDiag>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
   using V = typename Vec4<ST>::type;
   __shared__ __attribute__((aligned(16))) float lds[kBlock * RDV_OBS_DIM];   // 17,408 B: wave-private staging regions
-  const DevParams& P = A.P;
+  const DevParams& P = *A.P;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave_in_block = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -153,16 +153,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
     if (e.flags & FLAG_HALTED) {
       observation(P, e, r.obs);
       r.done = 1;
-      if (A.diag) {
-        Derived d; double corr_l[3];
-        derive(P, e, d, corr_l);
+      if (kDiag) {
+        Derived d;
+        derive(P, e, d);
         diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);
       }
     } else {
-      Derived d; double corr_l[3];
-      step_env<ST>(P, e, a, r, d, corr_l);
+      Derived d;
+      step_env<ST>(P, e, a, r, d);
       stepped = true;
-      if (A.diag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);
+      if (kDiag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);   // evaluator build only: keeps the training kernel short
     }
   }
 
@@ -262,12 +262,13 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
 
 // reset() for all envs or where mask != 0
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams P, void* ws_, int64_t n, const uint8_t* mask,
+__global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams* __restrict__ Pp, void* ws_, int64_t n, const uint8_t* mask,
                                                        float* obs, const double* tape, int32_t tape_depth, uint64_t seed,
                                                        uint64_t env_id_offset, int fresh) {
   using V = typename Vec4<ST>::type;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  const DevParams& P = *Pp;
   V* ws = reinterpret_cast<V*>(ws_);
   if (mask && !mask[i]) return;
   Env e;
@@ -288,11 +289,12 @@ enum { ACC_SET_STATE = 0, ACC_GET_STATE, ACC_GET_AUX, ACC_OBSERVE, ACC_DIAGNOSE 
 
 // state access / evaluator helpers (cold paths; one lane per env, row-major host-facing arrays)
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void* ws_, int64_t n, int what, const double* in,
+__global__ __launch_bounds__(kBlock) void access_kernel(const DevParams* __restrict__ Pp, void* ws_, int64_t n, int what, const double* in,
                                                         double* out, float* out_f32) {
   using V = typename Vec4<ST>::type;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
+  const DevParams& P = *Pp;
   V* ws = reinterpret_cast<V*>(ws_);
   Env e;
   load_env<ST>(ws, n, i, e);
@@ -315,8 +317,8 @@ __global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void*
     observation(P, e, o);
     for (int j = 0; j < RDV_OBS_DIM; ++j) out_f32[i * RDV_OBS_DIM + j] = o[j];
   } else {
-    Derived d; double corr_l[3];
-    derive(P, e, d, corr_l);
+    Derived d;
+    derive(P, e, d);
     diagnostics(P, e, d, out + i * RDV_DIAG_DIM);
   }
 }
@@ -341,6 +343,24 @@ static int fail(int code, const char* fmt, ...) {
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static inline int64_t n_waves(int64_t n) { return (n + kBlock - 1) / kBlock * (kBlock / kWave); }
 static inline int64_t chunk_bytes(int64_t n, int storage) { return align_up(kChunks * n * 4 * (storage == RDV_STORAGE_F64 ? 8 : 4), 256); }
+static inline int64_t stats_bytes(int64_t n) { return align_up(n_waves(n) * kStatWords * (int64_t)sizeof(uint64_t), 256); }
+static inline int64_t params_bytes() { return align_up((int64_t)sizeof(DevParams), 256); }
+
+// Largest integer k in [-100000, 100000] for which acos(k/1e5) > theta (strict) or >= theta; -100001 if there is none.
+// acos(k/1e5) is what general.py:179 evaluates for every cosine that rounds to k*1e-5, so comparing k with this
+// threshold is the reference's comparison, decided once on the host with the libm the oracle uses.
+static double largest_k_with_angle_above(double theta, bool strict) {
+  long lo = -100001, hi = 100001;   // predicate true at lo (virtual), false at hi (virtual); acos is decreasing in k
+  while (hi - lo > 1) {
+    const long mid = lo + (hi - lo) / 2;
+    const double ang = std::acos((double)mid / 1e5);
+    const bool above = strict ? (ang > theta) : (ang >= theta);
+    if (above) lo = mid; else hi = mid;
+  }
+  return (double)lo;
+}
+
+static inline double norm3h(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
 static void derive_params(const RdvParams& p, DevParams& d) {
   std::memset(&d, 0, sizeof d);
@@ -352,21 +372,37 @@ static void derive_params(const RdvParams& p, DevParams& d) {
   d.phi_vxx = 3 * n * s;         d.phi_vxvx = c;                d.phi_vxvy = 2 * s;
   d.phi_vyx = -6 * n * (1 - c);  d.phi_vyvx = -2 * s;           d.phi_vyvy = 4 * c - 3;
   d.phi_vzz = -n * s;            d.phi_vzvz = c;
-  d.dt = p.dt; d.half_dt = 0.5 * p.dt; d.t_max = p.t_max;
+  d.dt = p.dt; d.half_dt = 0.5 * p.dt;
   d.max_delta_w = p.max_delta_w;
   d.max_delta_v_f32 = (float)p.max_delta_v;
   d.fuel_scale_f32 = (float)(p.dt * p.fuel_coef);
   d.fuel_div_f32 = (float)(3 * p.max_delta_v);
-  d.obs_lo_r = -p.max_axial_distance; d.obs_span_r = p.max_axial_distance - (-p.max_axial_distance);
-  d.obs_lo_v = -p.max_axial_speed;    d.obs_span_v = p.max_axial_speed - (-p.max_axial_speed);
-  d.obs_lo_w = -p.max_wc;             d.obs_span_w = p.max_wc - (-p.max_wc);
-  d.max_attitude_error = p.max_attitude_error; d.koz_radius = p.koz_radius; d.corridor_half_angle = p.corridor_half_angle;
+  {  // :193 t = round(t + dt, 3), :368 t >= t_max  ->  first step count whose rounded time reaches t_max
+    long long k = (long long)std::floor(p.t_max / p.dt) - 3;
+    if (k < 0) k = 0;
+    while (k < 2147483647LL && std::rint((double)k * p.dt * 1e3) / 1e3 < p.t_max) ++k;
+    d.k_time = (int32_t)k;
+  }
+  d.obs_lo_r = -p.max_axial_distance; d.obs_scale_r = 2.0 / (p.max_axial_distance - (-p.max_axial_distance));
+  d.obs_lo_v = -p.max_axial_speed;    d.obs_scale_v = 2.0 / (p.max_axial_speed - (-p.max_axial_speed));
+  d.obs_lo_w = -p.max_wc;             d.obs_scale_w = 2.0 / (p.max_wc - (-p.max_wc));
+  d.koz_radius = p.koz_radius; d.corridor_half_angle = p.corridor_half_angle;
+  d.inv_max_attitude_error = 1.0 / p.max_attitude_error; d.inv_max_rd_error = 1.0 / p.max_rd_error; d.inv_max_qd_error = 1.0 / p.max_qd_error;
   for (int i = 0; i < 3; ++i) { d.corridor_axis[i] = p.corridor_axis[i]; d.capture_axis[i] = p.capture_axis[i]; d.rd[i] = p.rd[i]; }
-  d.max_rd_error = p.max_rd_error; d.max_vd_error = p.max_vd_error; d.max_qd_error = p.max_qd_error; d.max_wd_error = p.max_wd_error;
+  d.inv_corridor_norm = 1.0 / norm3h(p.corridor_axis); d.inv_capture_norm = 1.0 / norm3h(p.capture_axis);
+  d.max_rd_error2 = p.max_rd_error * p.max_rd_error; d.max_vd_error2 = p.max_vd_error * p.max_vd_error; d.max_wd_error2 = p.max_wd_error * p.max_wd_error;
+  d.kc_coll_max = largest_k_with_angle_above(p.corridor_half_angle, true);        // :401  angle >  half_angle
+  d.ka_done_max = largest_k_with_angle_above(p.max_attitude_error, true);         // :370  att   >  max_attitude_error
+  d.ka_succ_min = largest_k_with_angle_above(p.max_qd_error, true) + 1.0;         // :417  att   <= max_qd_error
+  d.ka_bonus_min = largest_k_with_angle_above(p.max_qd_error, false) + 1.0;       // :350  att   <  max_qd_error
   d.bubble_radius0 = p.bubble_radius0; d.bubble_decrease_rate = p.bubble_decrease_rate; d.bubble_min = p.bubble_min;
   d.att_term = p.dt * p.att_coef; d.coll_term = p.dt * p.collision_coef; d.bonus_term = p.dt * p.bonus_coef;
   for (int i = 0; i < 3; ++i) { d.nominal_rc0[i] = p.nominal_rc0[i]; d.nominal_vc0[i] = p.nominal_vc0[i]; d.nominal_wc0[i] = p.nominal_wc0[i]; d.nominal_wt0[i] = p.nominal_wt0[i]; }
-  for (int i = 0; i < 4; ++i) { d.nominal_qc0[i] = p.nominal_qc0[i]; d.nominal_qt0[i] = p.nominal_qt0[i]; }
+  {  // quat_product normalises its factors (quaternions.py:159-160)
+    const double mc = std::sqrt(p.nominal_qc0[0] * p.nominal_qc0[0] + p.nominal_qc0[1] * p.nominal_qc0[1] + p.nominal_qc0[2] * p.nominal_qc0[2] + p.nominal_qc0[3] * p.nominal_qc0[3]);
+    const double mt = std::sqrt(p.nominal_qt0[0] * p.nominal_qt0[0] + p.nominal_qt0[1] * p.nominal_qt0[1] + p.nominal_qt0[2] * p.nominal_qt0[2] + p.nominal_qt0[3] * p.nominal_qt0[3]);
+    for (int i = 0; i < 4; ++i) { d.nominal_qc0[i] = p.nominal_qc0[i] / mc; d.nominal_qt0[i] = p.nominal_qt0[i] / mt; }
+  }
   d.rc0_range = p.rc0_range; d.vc0_range = p.vc0_range; d.qc0_range = p.qc0_range;
   d.wc0_range = p.wc0_range; d.qt0_range = p.qt0_range; d.wt0_range = p.wt0_range;
 }
@@ -392,6 +428,7 @@ struct RdvEnvBatch {
   uint64_t seed, env_id_offset;
   void* ws;          // chunks
   uint64_t* stats;   // slots
+  DevParams* dev_params;   // device copy of `dev`
   bool own_ws;
   bool fresh;        // no reset yet since create/seed
   const double* tape;
@@ -447,7 +484,7 @@ int rdv_params_validate(const RdvParams* p) {
 
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
   if (n_envs <= 0 || (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64)) return -1;
-  return chunk_bytes(n_envs, storage) + n_waves(n_envs) * kStatWords * (int64_t)sizeof(uint64_t);
+  return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes();
 }
 
 int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
@@ -478,8 +515,10 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
     h->own_ws = true;
   }
   h->stats = reinterpret_cast<uint64_t*>(static_cast<char*>(h->ws) + chunk_bytes(n_envs, storage));
+  h->dev_params = reinterpret_cast<DevParams*>(reinterpret_cast<char*>(h->stats) + stats_bytes(n_envs));
   hipError_t err = hipMemset(h->ws, 0, (size_t)bytes);
-  if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(err)); }
+  if (err == hipSuccess) err = hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice);
+  if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset/hipMemcpy of the workspace failed: %s", hipGetErrorString(err)); }
   h->host_slots.resize((size_t)(n_waves(n_envs) * kStatWords));
   *out = h;
   return RDV_OK;
@@ -498,7 +537,10 @@ int rdv_destroy(rdv_handle h) {
 int rdv_set_params(rdv_handle h, const RdvParams* p) {
   RDV_CHECK_HANDLE(h);
   if (int rc = rdv_params_validate(p)) return rc;
+  DeviceGuard guard(h->device);
   h->params = *p; derive_params(*p, h->dev);
+  // blocking copy on the legacy default stream: ordered after work already enqueued on blocking streams
+  RDV_HIP(hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice));
   return RDV_OK;
 }
 int rdv_get_params(rdv_handle h, RdvParams* out) {
@@ -528,9 +570,9 @@ int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream) {
   const int fresh = (h->fresh && !mask) ? 1 : 0;
   if (h->fresh && mask) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_reset: the first reset after create/seed must cover all envs (mask = NULL)");
   if (h->storage == RDV_STORAGE_F32)
-    hipLaunchKernelGGL(reset_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
+    hipLaunchKernelGGL(reset_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
   else
-    hipLaunchKernelGGL(reset_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
+    hipLaunchKernelGGL(reset_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
   RDV_HIP(hipGetLastError());
   h->fresh = false;
   return RDV_OK;
@@ -546,14 +588,20 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   if (out->diag && (reinterpret_cast<uintptr_t>(out->diag) & 7)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: diag must be 8-byte aligned");
   DeviceGuard guard(h->device);
   StepArgs A;
-  A.P = h->dev; A.ws = h->ws; A.stats = h->stats; A.actions = actions;
+  A.P = h->dev_params; A.ws = h->ws; A.stats = h->stats; A.actions = actions;
   A.obs = out->obs; A.reward = out->reward; A.done = out->done; A.terminal_obs = out->terminal_obs;
   A.episode_return = out->episode_return; A.episode_length = out->episode_length; A.done_reason = out->done_reason;
   A.diag = out->diag; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(step_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, A);
-  else hipLaunchKernelGGL(step_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, A);
+  const dim3 grid = grid_for(h->n), block(kBlock);
+  if (h->storage == RDV_STORAGE_F32) {
+    if (A.diag) hipLaunchKernelGGL((step_kernel<float, true>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((step_kernel<float, false>), grid, block, 0, s, A);
+  } else {
+    if (A.diag) hipLaunchKernelGGL((step_kernel<double, true>), grid, block, 0, s, A);
+    else hipLaunchKernelGGL((step_kernel<double, false>), grid, block, 0, s, A);
+  }
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
@@ -561,8 +609,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
 static int access(rdv_handle h, int what, const double* in, double* out, float* out_f32, void* stream) {
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(access_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
-  else hipLaunchKernelGGL(access_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(access_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, what, in, out, out_f32);
+  else hipLaunchKernelGGL(access_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, what, in, out, out_f32);
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }

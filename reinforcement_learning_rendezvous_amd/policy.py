@@ -1,0 +1,69 @@
+"""
+The SB3 MlpPolicy actor of the reference's shipped checkpoint (models/mlp_model_best.zip -> policy.pth):
+``a = clip(W3 tanh(W2 tanh(W1 obs + b1) + b2) + b3, -1, 1)``, 17-64-64-6, float32, plus the stochastic rollout form
+``a = clip(mean + exp(log_std) * N(0,1), -1, 1)`` that SB3's collect_rollouts uses (main.py:33-46 builds it with
+``activation_fn=Tanh``).  Runs in PyTorch on whatever device the observations live on; it is not part of the env kernel.
+"""
+import io
+import zipfile
+
+import numpy as np
+import torch
+
+_KEYS = ["mlp_extractor.policy_net.0.weight", "mlp_extractor.policy_net.0.bias", "mlp_extractor.policy_net.2.weight",
+         "mlp_extractor.policy_net.2.bias", "action_net.weight", "action_net.bias", "log_std"]
+
+
+class MlpPolicy(torch.nn.Module):
+    def __init__(self, weights=None, obs_dim=17, hidden=64, act_dim=6, seed=0):
+        super().__init__()
+        self.l1 = torch.nn.Linear(obs_dim, hidden)
+        self.l2 = torch.nn.Linear(hidden, hidden)
+        self.l3 = torch.nn.Linear(hidden, act_dim)
+        self.log_std = torch.nn.Parameter(torch.zeros(act_dim))
+        if weights is None:
+            # random init of the same architecture (bench.py when the checkpoint fixture is absent)
+            g = torch.Generator().manual_seed(seed)
+            for lin, gain in ((self.l1, 2 ** 0.5), (self.l2, 2 ** 0.5), (self.l3, 0.01)):
+                torch.nn.init.orthogonal_(lin.weight, gain=gain, generator=g)
+                torch.nn.init.zeros_(lin.bias)
+        else:
+            w = {k: torch.as_tensor(np.asarray(weights[k]), dtype=torch.float32) for k in _KEYS}
+            with torch.no_grad():
+                self.l1.weight.copy_(w[_KEYS[0]]); self.l1.bias.copy_(w[_KEYS[1]])
+                self.l2.weight.copy_(w[_KEYS[2]]); self.l2.bias.copy_(w[_KEYS[3]])
+                self.l3.weight.copy_(w[_KEYS[4]]); self.l3.bias.copy_(w[_KEYS[5]])
+                self.log_std.copy_(w[_KEYS[6]])
+        for p in self.parameters():
+            p.requires_grad_(False)
+
+    @classmethod
+    def from_npz(cls, path):
+        """Weights extracted from policy.pth as plain arrays (tests/golden/mlp_policy.npz)."""
+        return cls(np.load(path, allow_pickle=False))
+
+    @classmethod
+    def from_sb3_zip(cls, path):
+        """An SB3 checkpoint zip as `model.save()` writes it; policy.pth is read with weights_only=True (nothing is unpickled)."""
+        with zipfile.ZipFile(path) as z:
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), weights_only=True, map_location="cpu")
+        return cls({k: v.numpy() for k, v in sd.items()})
+
+    @torch.no_grad()
+    def mean(self, obs):
+        return self.l3(torch.tanh(self.l2(torch.tanh(self.l1(obs)))))
+
+    @torch.no_grad()
+    def act(self, obs, deterministic=True, generator=None):
+        """SB3 ``predict``: the distribution mean (or a sample), clipped to the action Box."""
+        a = self.mean(obs)
+        if not deterministic:
+            noise = torch.randn(a.shape, dtype=a.dtype, device=a.device, generator=generator)
+            a = a + torch.exp(self.log_std) * noise
+        return torch.clamp(a, -1.0, 1.0)
+
+    def predict(self, observation, state=None, episode_start=None, deterministic=True):
+        """SB3-compatible signature (monte_carlo.py:130-135) for NumPy observations."""
+        dev = self.l1.weight.device
+        obs = torch.as_tensor(np.asarray(observation), dtype=torch.float32, device=dev)
+        return self.act(obs, deterministic=deterministic).cpu().numpy(), state
