@@ -57,9 +57,17 @@ typedef enum RdvOnDone {
   RDV_ON_DONE_HALT = 1    /* env freezes: later steps leave it untouched and report done=1, reward=0 */
 } RdvOnDone;
 
+/* Which step kernel rdv_step launches.  Both give the same results (same arithmetic); they differ in how the work of a
+ * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 131072) and FUSED above. */
+typedef enum RdvKernelVariant {
+  RDV_VARIANT_AUTO = 0,
+  RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs, resets run divergently in-lane */
+  RDV_VARIANT_SPLIT = 2   /* step waves + service waves (next initial states, statistics, observation stores) */
+} RdvKernelVariant;
+
 /*
  * Environment parameters = the attributes RendezvousEnv.__init__ derives (rendezvous_env.py:52-126)
- * plus the reward_kwargs of get_bubble_reward (:313).  All doubles, no padding, 58 of them.
+ * plus the reward_kwargs of get_bubble_reward (:313).  All doubles, no padding, 57 of them.
  * rdv_params_default() fills the reference defaults; the Python host re-derives dependent values
  * (max_axial_distance, bubble_*, n) from user kwargs exactly as the reference ctor does.
  */
@@ -115,8 +123,9 @@ typedef struct RdvStepOut {
   double*  diag;            /* [N,8]  nullable; evaluator diagnostics of the post-step (pre-reset) state, RDV_DIAG_DIM */
 } RdvStepOut;
 
-/* Episode statistics accumulated on device with one wavefront reduction + one atomic per wave and step
- * (the list logged by custom/custom_callbacks.py:285-298).  Counters are exact; sums are fp64 atomics. */
+/* Episode statistics accumulated on device (the list logged by custom/custom_callbacks.py:285-298): per step one
+ * wavefront reduction per 64 envs into that wave's private 128-byte slot (no same-address atomics); rdv_get_stats sums
+ * the slots on the host in a fixed order, so the counters are exact and the fp64 sums reproducible. */
 typedef struct RdvStats {
   uint64_t env_steps;          /* env transitions executed */
   uint64_t episodes;           /* finished episodes */
@@ -164,6 +173,9 @@ int rdv_seed(rdv_handle h, uint64_t seed);
  * be replayed on device).  depth = 0 / tape = NULL returns to RNG resets.  The tape must outlive its use.
  */
 int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth);
+
+/* Tuning: force a kernel variant (RdvKernelVariant).  Results do not depend on it. */
+int rdv_set_kernel_variant(rdv_handle h, int variant);
 
 /* RendezvousEnv.reset() (:223-270) for every env, or for envs with mask[i] != 0.  obs_out [N,17] nullable. */
 int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream);

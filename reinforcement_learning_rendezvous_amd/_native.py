@@ -15,6 +15,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 STORAGE_F32, STORAGE_F64 = 0, 1
 ON_DONE_RESET, ON_DONE_HALT = 0, 1
+VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT = 0, 1, 2
 OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM = 17, 6, 20, 8, 8
 
 ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVICE", -3: "RDV_ERR_HIP",
@@ -23,6 +24,7 @@ ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVI
 # every symbol include/rdv.h declares (tests/test_abi.py checks the list against the header and the .so)
 SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
+           "rdv_set_kernel_variant",
            "rdv_reset", "rdv_step", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_observe", "rdv_diagnose",
            "rdv_get_stats", "rdv_num_envs"]
 
@@ -90,6 +92,7 @@ def lib():
         "rdv_get_params": (C.c_int, [vp, PP]),
         "rdv_seed": (C.c_int, [vp, u64]),
         "rdv_set_reset_tape": (C.c_int, [vp, vp, i32]),
+        "rdv_set_kernel_variant": (C.c_int, [vp, C.c_int]),
         "rdv_reset": (C.c_int, [vp, vp, vp, vp]),
         "rdv_step": (C.c_int, [vp, vp, C.POINTER(StepOut), vp]),
         "rdv_set_state": (C.c_int, [vp, vp, vp]),

@@ -16,12 +16,14 @@ from .params import EnvParams, make_params
 
 _STORAGE = {"f32": N.STORAGE_F32, "f64": N.STORAGE_F64, N.STORAGE_F32: N.STORAGE_F32, N.STORAGE_F64: N.STORAGE_F64}
 _ON_DONE = {"reset": N.ON_DONE_RESET, "halt": N.ON_DONE_HALT}
+_VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT}
 
 
 class RendezvousBatch:
     def __init__(self, num_envs, params: EnvParams = None, device="cuda:0", storage="f32", on_done="reset", seed=0,
-                 env_id_offset=0, **env_kwargs):
-        """``env_kwargs`` are the keyword arguments of the reference constructor (rendezvous_env.py:17-37)."""
+                 env_id_offset=0, variant="auto", **env_kwargs):
+        """``env_kwargs`` are the keyword arguments of the reference constructor (rendezvous_env.py:17-37).
+        ``variant`` ("auto" | "fused" | "split") selects the step kernel layout; results do not depend on it."""
         if params is not None and env_kwargs:
             raise TypeError("pass either params or the reference constructor's keyword arguments, not both")
         self.params = params.copy() if params is not None else make_params(**env_kwargs)
@@ -44,6 +46,7 @@ class RendezvousBatch:
         N.check(self._lib.rdv_create(C.byref(self.params), self.num_envs, dev_index, self.storage, self.on_done,
                                      C.c_uint64(seed), C.c_uint64(env_id_offset), self._ws.data_ptr(),
                                      C.byref(self._h)))
+        N.check(self._lib.rdv_set_kernel_variant(self._h, _VARIANT[variant]))
         n, dev = self.num_envs, self.device
         self.obs = torch.zeros((n, N.OBS_DIM), dtype=torch.float32, device=dev)
         self.reward = torch.zeros(n, dtype=torch.float32, device=dev)

@@ -290,9 +290,10 @@ __device__ __forceinline__ void deviate(const double* axis, double theta, const 
   o[3] = fma(a[0], b[3], fma(b[0], a[3], fma(a[1], b[2], -a[2] * b[1])));
 }
 
-// reset (:223-270).  Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
+// reset (:223-262): the new state and its collided/success flags, from (seed, env id, e.episode) or from a tape row.
+// Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
 template <typename ST>
-__device__ __forceinline__ void reset_env(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
+__device__ __forceinline__ void reset_state(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
   if (tape_row) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) e.rc[i] = tape_row[i];
@@ -350,11 +351,22 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Env& e, uint64_t s
   const bool coll = in_koz(P, d);                                         // :261
   const bool succ = !coll && errors_ok(P, d);                             // :262
   e.flags = (coll ? FLAG_COLLIDED : 0u) | ((succ ? 1u : 0u) << SUCCESS_SHIFT);
-  e.bubble = canon(P.bubble_radius0, tag);                                // :263
+}
+
+// the bookkeeping half of reset (:263-266)
+template <typename ST>
+__device__ __forceinline__ void reset_aux(const DevParams& P, Env& e) {
+  e.bubble = canon(P.bubble_radius0, ST(0));                              // :263
   e.sum_dv = 0.0; e.sum_dw = 0.0;                                         // :264-265
   e.k = 0;                                                                // :266
   e.ep_ret = 0.0;
   e.episode += 1;
+}
+
+template <typename ST>
+__device__ __forceinline__ void reset_env(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
+  reset_state<ST>(P, e, seed, env_id, tape_row);
+  reset_aux<ST>(P, e);
 }
 
 struct StepResult {

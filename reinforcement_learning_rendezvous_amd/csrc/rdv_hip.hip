@@ -31,6 +31,7 @@ constexpr int kBlock = 256;             // 4 waves per workgroup
 constexpr int kWave = 64;
 constexpr int kChunks = 7;
 constexpr int kStatWords = 16;          // 128-byte slot per wave
+constexpr int64_t kSplitAutoMaxEnvs = 131072;   // at most ~2 waves per SIMD of 256 CUs x 4 SIMDs: the chip is not full
 enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
        ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
 
@@ -104,6 +105,141 @@ struct StepArgs {
   int32_t on_done;
 };
 
+// LDS exchanged inside ONE wave (wave-private region): LDS operations of a wave execute in issue order, so only the
+// compiler has to be kept from moving the reads above the writes.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// actions [64,6] of one wave: 3 coalesced float2 loads per lane -> wave-private LDS -> own row
+__device__ __forceinline__ void load_actions(const float* __restrict__ actions, int64_t wave_base, int64_t rows, int lane,
+                                             bool active, float* wl, float* a) {
+  const float* src = actions + wave_base * RDV_ACT_DIM;
+  const int64_t valid = rows * RDV_ACT_DIM;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const int idx = k * 128 + lane * 2;
+    if (idx + 1 < valid) {
+      *reinterpret_cast<float2*>(wl + idx) = *reinterpret_cast<const float2*>(src + idx);
+    } else if (idx < valid) {
+      wl[idx] = src[idx];
+    }
+  }
+  wave_lds_fence();
+#pragma unroll
+  for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? wl[lane * RDV_ACT_DIM + j] : 0.0f;
+  wave_lds_fence();   // the region is reused for the observations
+}
+
+// observations [64,17] of one wave: staged rows in LDS -> contiguous 16-byte-per-lane global stores
+__device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t wave_base, int64_t rows, int lane, const float* wl) {
+  if (rows <= 0) return;
+  float* dst = obs + wave_base * RDV_OBS_DIM;
+  if (rows == kWave) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int q = k * kWave + lane;
+      *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
+    }
+    if (lane < 16) {
+      const int q = 4 * kWave + lane;
+      *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
+    }
+  } else {   // ragged tail wave
+    const int64_t valid = rows * RDV_OBS_DIM;
+    for (int j = 0; j < RDV_OBS_DIM; ++j) {
+      const int idx = j * kWave + lane;
+      if (idx < valid) dst[idx] = wl[idx];
+    }
+  }
+}
+
+// Episode statistics of one wave of envs: wavefront reductions (ballot/popcount for the counters, butterfly sums for
+// the reals), then lanes 0..11 update the wave's private 128-byte slot with plain read-modify-writes.
+__device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, int lane, bool stepped, bool fin, int reason,
+                                             uint32_t flags, int k, double ep_ret, double sum_dv, double sum_dw) {
+  const unsigned long long m_step = __ballot(stepped);
+  const unsigned long long m_fin = __ballot(fin);
+  if (m_step == 0ull) return;   // wave-uniform
+  if (m_fin != 0ull) {
+    const unsigned long long m_succ = __ballot(fin && (flags >> SUCCESS_SHIFT) != 0u);
+    const unsigned long long m_coll = __ballot(fin && (flags & FLAG_COLLIDED));
+    const unsigned long long m_r1 = __ballot(fin && reason == 1), m_r2 = __ballot(fin && reason == 2);
+    const unsigned long long m_r3 = __ballot(fin && reason == 3), m_r4 = __ballot(fin && reason == 4);
+    const int s_len = wave_sum(fin ? k : 0);
+    const double s_ret = wave_sum(fin ? ep_ret : 0.0);
+    const double s_dv = wave_sum(fin ? sum_dv : 0.0);
+    const double s_dw = wave_sum(fin ? sum_dw : 0.0);
+    if (lane < 12) {
+      uint64_t iv = 0; double dv = 0.0;
+      switch (lane) {
+        case ST_STEPS: iv = __popcll(m_step); break;
+        case ST_EPISODES: iv = __popcll(m_fin); break;
+        case ST_SUCCESS: iv = __popcll(m_succ); break;
+        case ST_COLLIDED: iv = __popcll(m_coll); break;
+        case ST_REASON0: iv = __popcll(m_r1); break;
+        case ST_REASON1: iv = __popcll(m_r2); break;
+        case ST_REASON2: iv = __popcll(m_r3); break;
+        case ST_REASON3: iv = __popcll(m_r4); break;
+        case ST_SUM_LEN: iv = (uint64_t)s_len; break;
+        case ST_SUM_RET: dv = s_ret; break;
+        case ST_SUM_DV: dv = s_dv; break;
+        default: dv = s_dw; break;
+      }
+      if (lane <= ST_SUM_LEN) slot[lane] += iv;
+      else reinterpret_cast<double*>(slot)[lane] += dv;
+    }
+  } else if (lane == 0) {
+    slot[ST_STEPS] += __popcll(m_step);
+  }
+}
+
+// per-env outputs of a transition (coalesced 4-/1-byte stores; the sparse ones only where an episode ended)
+__device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i, bool active, bool fin, const StepResult& r,
+                                                   const Env& e) {
+  if (active) {
+    A.reward[i] = r.reward;
+    A.done[i] = (uint8_t)r.done;
+    if (A.done_reason) A.done_reason[i] = (uint8_t)r.reason;
+  }
+  if (fin) {
+    if (A.terminal_obs) {
+      float* t = A.terminal_obs + i * RDV_OBS_DIM;
+#pragma unroll
+      for (int j = 0; j < RDV_OBS_DIM; ++j) t[j] = r.obs[j];
+    }
+    if (A.episode_return) A.episode_return[i] = (float)e.ep_ret;
+    if (A.episode_length) A.episode_length[i] = e.k;
+  }
+}
+
+// step one lane's env (or report a halted one); returns whether a transition was executed
+template <typename ST, bool kDiag>
+__device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, int64_t i, bool active, Env& e, const float* a,
+                                        StepResult& r) {
+  r.done = 0; r.reason = 0; r.reward = 0.0f;
+#pragma unroll
+  for (int j = 0; j < RDV_OBS_DIM; ++j) r.obs[j] = 0.0f;
+  bool stepped = false;
+  if (active) {
+    Derived d;
+    if (e.flags & FLAG_HALTED) {
+      observation(P, e, r.obs);
+      r.done = 1;
+      if (kDiag) { derive(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
+    } else {
+      step_env<ST>(P, e, a, r, d);
+      stepped = true;
+      if (kDiag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);   // evaluator build only: keeps the training kernel short
+    }
+  }
+  return stepped;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).
+// The right shape when the chip is full (several waves per SIMD): no work is done twice.
 template <typename ST, bool kDiag>
 __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
   using V = typename Vec4<ST>::type;
@@ -119,106 +255,19 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
   float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
   V* ws = reinterpret_cast<V*>(A.ws);
 
-  // ---- state: 7 x 16-byte-per-lane loads, issued before anything depends on them
   Env e;
-  if (active) load_env<ST>(ws, n, i, e);
-
-  // ---- actions [64,6] of this wave: 3 coalesced float2 loads per lane -> LDS -> own row
-  {
-    const float* src = A.actions + wave_base * RDV_ACT_DIM;
-    const int64_t valid = rows * RDV_ACT_DIM;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int idx = k * 128 + lane * 2;
-      if (idx + 1 < valid) {
-        const float2 v = *reinterpret_cast<const float2*>(src + idx);
-        *reinterpret_cast<float2*>(wl + idx) = v;
-      } else if (idx < valid) {
-        wl[idx] = src[idx];
-      }
-    }
-  }
-  __syncthreads();
+  if (active) load_env<ST>(ws, n, i, e);   // 7 x 16-byte-per-lane loads, issued before anything depends on them
   float a[RDV_ACT_DIM];
-#pragma unroll
-  for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? wl[lane * RDV_ACT_DIM + j] : 0.0f;
-  __syncthreads();   // the region is reused for the observations below
+  load_actions(A.actions, wave_base, rows, lane, active, wl, a);
 
   StepResult r;
-  r.done = 0; r.reason = 0; r.reward = 0.0f;
-#pragma unroll
-  for (int j = 0; j < RDV_OBS_DIM; ++j) r.obs[j] = 0.0f;
-  bool stepped = false, did_reset = false;
-  if (active) {
-    if (e.flags & FLAG_HALTED) {
-      observation(P, e, r.obs);
-      r.done = 1;
-      if (kDiag) {
-        Derived d;
-        derive(P, e, d);
-        diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);
-      }
-    } else {
-      Derived d;
-      step_env<ST>(P, e, a, r, d);
-      stepped = true;
-      if (kDiag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);   // evaluator build only: keeps the training kernel short
-    }
-  }
-
-  // ---- episode statistics: wavefront reductions, then lanes 0..11 update this wave's private 128-byte slot
+  const bool stepped = advance<ST, kDiag>(A, P, i, active, e, a, r);
   const bool fin = stepped && r.done;
-  const unsigned long long m_step = __ballot(stepped);
-  const unsigned long long m_fin = __ballot(fin);
-  if (m_step != 0ull) {   // wave-uniform
-    uint64_t* slot = A.stats + ((uint64_t)blockIdx.x * (kBlock / kWave) + wave_in_block) * kStatWords;
-    if (m_fin != 0ull) {
-      const unsigned long long m_succ = __ballot(fin && (e.flags >> SUCCESS_SHIFT) != 0u);
-      const unsigned long long m_coll = __ballot(fin && (e.flags & FLAG_COLLIDED));
-      const unsigned long long m_r1 = __ballot(fin && r.reason == 1), m_r2 = __ballot(fin && r.reason == 2);
-      const unsigned long long m_r3 = __ballot(fin && r.reason == 3), m_r4 = __ballot(fin && r.reason == 4);
-      const int s_len = wave_sum(fin ? e.k : 0);
-      const double s_ret = wave_sum(fin ? e.ep_ret : 0.0);
-      const double s_dv = wave_sum(fin ? e.sum_dv : 0.0);
-      const double s_dw = wave_sum(fin ? e.sum_dw : 0.0);
-      if (lane < 12) {
-        uint64_t iv = 0; double dv = 0.0;
-        switch (lane) {
-          case ST_STEPS: iv = __popcll(m_step); break;
-          case ST_EPISODES: iv = __popcll(m_fin); break;
-          case ST_SUCCESS: iv = __popcll(m_succ); break;
-          case ST_COLLIDED: iv = __popcll(m_coll); break;
-          case ST_REASON0: iv = __popcll(m_r1); break;
-          case ST_REASON1: iv = __popcll(m_r2); break;
-          case ST_REASON2: iv = __popcll(m_r3); break;
-          case ST_REASON3: iv = __popcll(m_r4); break;
-          case ST_SUM_LEN: iv = (uint64_t)s_len; break;
-          case ST_SUM_RET: dv = s_ret; break;
-          case ST_SUM_DV: dv = s_dv; break;
-          default: dv = s_dw; break;
-        }
-        if (lane <= ST_SUM_LEN) slot[lane] += iv;
-        else reinterpret_cast<double*>(slot)[lane] += dv;
-      }
-    } else if (lane == 0) {
-      slot[ST_STEPS] += __popcll(m_step);
-    }
-  }
-
-  // ---- per-env outputs of the transition
-  if (active) {
-    A.reward[i] = r.reward;
-    A.done[i] = (uint8_t)r.done;
-    if (A.done_reason) A.done_reason[i] = (uint8_t)r.reason;
-  }
+  stats_update(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret,
+               e.sum_dv, e.sum_dw);
+  store_step_outputs(A, i, active, fin, r, e);
+  bool did_reset = false;
   if (fin) {
-    if (A.terminal_obs) {
-      float* t = A.terminal_obs + i * RDV_OBS_DIM;
-#pragma unroll
-      for (int j = 0; j < RDV_OBS_DIM; ++j) t[j] = r.obs[j];
-    }
-    if (A.episode_return) A.episode_return[i] = (float)e.ep_ret;
-    if (A.episode_length) A.episode_length[i] = e.k;
     if (A.on_done == RDV_ON_DONE_RESET) {
       // in-kernel auto-reset (SB3 DummyVecEnv semantics): the returned obs is the first obs of the next episode
       const double* row = nullptr;
@@ -226,38 +275,137 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
       reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, row);
       observation(P, e, r.obs);
       did_reset = true;
-    } else if (A.on_done == RDV_ON_DONE_HALT) {
+    } else {
       e.flags |= FLAG_HALTED;
     }
   }
-
-  // ---- observations: own row -> LDS (stride 17: conflict-free) -> contiguous 16-byte-per-lane stores
+  // observations: own row -> LDS (stride 17: conflict-free) -> contiguous stores
 #pragma unroll
   for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
-  __syncthreads();
-  if (rows > 0) {
-    float* dst = A.obs + wave_base * RDV_OBS_DIM;
-    if (rows == kWave) {
+  wave_lds_fence();
+  store_obs_rows(A.obs, wave_base, rows, lane, wl);
+  // state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt)
+  if (stepped) store_env<ST>(ws, n, i, e, did_reset);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-role variant for a chip that is NOT full (N <= ~128k envs leaves one wave per SIMD, and a lone wave issues at
+// half the SIMD's rate): a 256-thread workgroup owns 128 envs.  Waves 0-1 ("step waves") advance them; waves 2-3
+// ("service waves") run beside them on the same CU and take everything that does not depend on the step off the
+// critical path: they compute every env's NEXT initial state (it depends only on seed, env id and episode index) into
+// LDS while the step runs, then reduce the episode statistics and issue the coalesced observation stores.  A finished
+// env picks its new state up from LDS instead of running the reset in-lane.  Same arithmetic, same results as the
+// fused variant (tests run both); roughly twice the instructions issued, about half the critical path.
+constexpr int kSplitEnvs = 128;
+template <typename ST> struct ResetRec { static constexpr int kWords = 20 * (int)(sizeof(ST) / 4) + 1; };   // odd stride: conflict-free
+constexpr int kFinWords = 7;   // meta word + ep_return, sum_dv, sum_dw as fp64
+
+template <typename ST, bool kDiag>
+__global__ __launch_bounds__(kBlock) void step_kernel_split(const StepArgs A) {
+  using V = typename Vec4<ST>::type;
+  constexpr int kRec = ResetRec<ST>::kWords;
+  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // actions, then observations
+  __shared__ uint32_t recs[kSplitEnvs * kRec];                                       // next initial state per env
+  __shared__ uint32_t fins[kSplitEnvs * kFinWords];                                  // statistics inputs per env
+  const DevParams& P = *A.P;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x >> 6;
+  const bool step_role = wv < 2;
+  const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);          // both roles: the env this lane is responsible for
+  const int64_t i = (int64_t)blockIdx.x * kSplitEnvs + slot_in_block;
+  const int64_t wave_base = i - lane;
+  const int64_t n = A.n;
+  const bool active = i < n;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  float* wl = stage + (wv & 1) * (kWave * RDV_OBS_DIM);
+  uint32_t* rec = recs + slot_in_block * kRec;
+  uint32_t* fr = fins + slot_in_block * kFinWords;
+  V* ws = reinterpret_cast<V*>(A.ws);
+  const bool resets = A.on_done == RDV_ON_DONE_RESET;
+
+  Env e;
+  StepResult r;
+  bool stepped = false, fin = false, did_reset = false;
+  if (step_role) {
+    if (active) load_env<ST>(ws, n, i, e);
+    float a[RDV_ACT_DIM];
+    load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+    stepped = advance<ST, kDiag>(A, P, i, active, e, a, r);
+    fin = stepped && r.done;
+    // statistics inputs for the service wave
+    fr[0] = (stepped ? 1u : 0u) | (fin ? 2u : 0u) | ((uint32_t)r.reason << 2) | (((e.flags >> SUCCESS_SHIFT) != 0u) ? 32u : 0u) |
+            ((e.flags & FLAG_COLLIDED) ? 64u : 0u) | ((uint32_t)e.k << 8);
+    if (fin) {
+      const unsigned long long b0 = (unsigned long long)__double_as_longlong(e.ep_ret), b1 = (unsigned long long)__double_as_longlong(e.sum_dv),
+                               b2 = (unsigned long long)__double_as_longlong(e.sum_dw);
+      fr[1] = (uint32_t)b0; fr[2] = (uint32_t)(b0 >> 32); fr[3] = (uint32_t)b1; fr[4] = (uint32_t)(b1 >> 32);
+      fr[5] = (uint32_t)b2; fr[6] = (uint32_t)(b2 >> 32);
+    }
+    store_step_outputs(A, i, active, fin, r, e);
+  } else if (resets && active) {
+    // service wave: the env's next initial state, computed while the step waves work
+    const V c5 = ws[5 * n + i];
+    Env ne;
+    ne.episode = s2u(c5.w);
+    const double* row = nullptr;
+    if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
+    reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+    const double* st = ne.rc;   // rc vc qc wc qt wt are 20 contiguous doubles
+    if (sizeof(ST) == 4) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int q = k * kWave + lane;
-        *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
-      }
-      if (lane < 16) {
-        const int q = 4 * kWave + lane;
-        *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
-      }
-    } else {   // ragged tail wave
-      const int64_t valid = rows * RDV_OBS_DIM;
-      for (int j = 0; j < RDV_OBS_DIM; ++j) {
-        const int idx = j * kWave + lane;
-        if (idx < valid) dst[idx] = wl[idx];
+      for (int j = 0; j < 20; ++j) rec[j] = __float_as_uint((float)st[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 20; ++j) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(st[j]);
+        rec[2 * j] = (uint32_t)b; rec[2 * j + 1] = (uint32_t)(b >> 32);
       }
     }
+    rec[kRec - 1] = ne.flags;
   }
+  __syncthreads();   // B1: next initial states and statistics inputs are in LDS
 
-  // ---- state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt)
-  if (stepped) store_env<ST>(ws, n, i, e, did_reset);
+  if (step_role) {
+    if (fin) {
+      if (resets) {   // auto-reset (SB3 DummyVecEnv semantics): adopt the precomputed state
+        double* st = e.rc;
+        if (sizeof(ST) == 4) {
+#pragma unroll
+          for (int j = 0; j < 20; ++j) st[j] = (double)__uint_as_float(rec[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 20; ++j) st[j] = __longlong_as_double((long long)(((unsigned long long)rec[2 * j + 1] << 32) | rec[2 * j]));
+        }
+        e.flags = rec[kRec - 1];
+        reset_aux<ST>(P, e);
+        observation(P, e, r.obs);
+        did_reset = true;
+      } else {
+        e.flags |= FLAG_HALTED;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
+  } else {
+    const uint32_t meta = fr[0];
+    const bool s_stepped = active && (meta & 1u), s_fin = active && (meta & 2u);
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
+    if (s_fin) {
+      v0 = __longlong_as_double((long long)(((unsigned long long)fr[2] << 32) | fr[1]));
+      v1 = __longlong_as_double((long long)(((unsigned long long)fr[4] << 32) | fr[3]));
+      v2 = __longlong_as_double((long long)(((unsigned long long)fr[6] << 32) | fr[5]));
+    }
+    const uint32_t fl = ((meta & 32u) ? (1u << SUCCESS_SHIFT) : 0u) | ((meta & 64u) ? FLAG_COLLIDED : 0u);
+    stats_update(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, lane, s_stepped, s_fin, (int)((meta >> 2) & 7u), fl,
+                 (int)(meta >> 8), v0, v1, v2);
+  }
+  __syncthreads();   // B2: the observation rows (reset ones included) are staged
+
+  if (step_role) {
+    if (stepped) store_env<ST>(ws, n, i, e, did_reset);
+  } else {
+    store_obs_rows(A.obs, wave_base, rows, lane, wl);
+  }
 }
 
 // reset() for all envs or where mask != 0
@@ -433,6 +581,7 @@ struct RdvEnvBatch {
   bool fresh;        // no reset yet since create/seed
   const double* tape;
   int32_t tape_depth;
+  int variant;       // RdvKernelVariant
   std::vector<uint64_t> host_slots;
 };
 static constexpr uint32_t kMagic = 0x52445631u;   // "RDV1"
@@ -506,7 +655,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   if (!h) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_create: host allocation failed");
   h->magic = kMagic; h->params = *params; derive_params(*params, h->dev);
   h->n = n_envs; h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
-  h->tape = nullptr; h->tape_depth = 0; h->fresh = true;
+  h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
   if (workspace) { h->ws = workspace; h->own_ws = false; }
   else {
@@ -554,6 +703,13 @@ int rdv_seed(rdv_handle h, uint64_t seed) {
   h->seed = seed; h->fresh = true;
   return RDV_OK;
 }
+int rdv_set_kernel_variant(rdv_handle h, int variant) {
+  RDV_CHECK_HANDLE(h);
+  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_kernel_variant: bad variant %d", variant);
+  h->variant = variant;
+  return RDV_OK;
+}
 int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth) {
   RDV_CHECK_HANDLE(h);
   if ((tape == nullptr) != (depth <= 0)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_reset_tape: tape and depth must both be set or both be empty");
@@ -594,14 +750,22 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   A.diag = out->diag; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const dim3 grid = grid_for(h->n), block(kBlock);
-  if (h->storage == RDV_STORAGE_F32) {
-    if (A.diag) hipLaunchKernelGGL((step_kernel<float, true>), grid, block, 0, s, A);
-    else hipLaunchKernelGGL((step_kernel<float, false>), grid, block, 0, s, A);
-  } else {
-    if (A.diag) hipLaunchKernelGGL((step_kernel<double, true>), grid, block, 0, s, A);
-    else hipLaunchKernelGGL((step_kernel<double, false>), grid, block, 0, s, A);
-  }
+  const bool split = h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs);
+  const dim3 block(kBlock);
+  const dim3 grid = split ? dim3((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)) : grid_for(h->n);
+#define RDV_LAUNCH_STEP(KERNEL)                                                         \
+  do {                                                                                  \
+    if (h->storage == RDV_STORAGE_F32) {                                                \
+      if (A.diag) hipLaunchKernelGGL((KERNEL<float, true>), grid, block, 0, s, A);      \
+      else hipLaunchKernelGGL((KERNEL<float, false>), grid, block, 0, s, A);            \
+    } else {                                                                            \
+      if (A.diag) hipLaunchKernelGGL((KERNEL<double, true>), grid, block, 0, s, A);     \
+      else hipLaunchKernelGGL((KERNEL<double, false>), grid, block, 0, s, A);           \
+    }                                                                                   \
+  } while (0)
+  if (split) RDV_LAUNCH_STEP(step_kernel_split);
+  else RDV_LAUNCH_STEP(step_kernel);
+#undef RDV_LAUNCH_STEP
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }

@@ -31,14 +31,15 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+@pytest.mark.parametrize("variant", ["fused", "split"])
 @pytest.mark.parametrize("name", SCENARIOS)
-def test_golden_transitions_fp64_storage(name):
+def test_golden_transitions_fp64_storage(name, variant):
     """HIP kernel (parity mode) vs the reference's own recorded transitions."""
     g = load_golden(f"steps_{name}.npz")
     p, _ = params_from_note(g["env_kwargs_json"])
     T, E = g["actions"].shape[:2]
     halt = name.startswith("B")
-    env = _batch(E, params=p, storage="f64", on_done="halt" if halt else "reset")
+    env = _batch(E, params=p, storage="f64", on_done="halt" if halt else "reset", variant=variant)
     if not halt:
         env.set_reset_tape(torch.from_numpy(np.nan_to_num(g["tape"])))
     obs = _np(env.reset())
@@ -76,15 +77,16 @@ def test_golden_transitions_fp64_storage(name):
     env.close()
 
 
+@pytest.mark.parametrize("variant", ["fused", "split"])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["A_random", "C_variant", "D_stochastic"])
-def test_golden_actions_vs_oracle(name, storage):
+def test_golden_actions_vs_oracle(name, storage, variant):
     """Same tapes and action sequences, HIP vs oracle in the same storage precision (covers fp32 production mode)."""
     g = load_golden(f"steps_{name}.npz")
     p, op = params_from_note(g["env_kwargs_json"])
     T, E = g["actions"].shape[:2]
     tape = np.nan_to_num(g["tape"])
-    env = _batch(E, params=p, storage=storage)
+    env = _batch(E, params=p, storage=storage, variant=variant)
     env.set_reset_tape(torch.from_numpy(tape))
     orc = oracle.OracleBatch(E, op, storage=oracle.STORAGE_F32 if storage == "f32" else oracle.STORAGE_F64, tape=tape)
     np.testing.assert_array_equal(_np(env.reset()), orc.reset())
@@ -119,11 +121,12 @@ def _compare_run(env, orc, action_list, storage, check_every=1):
         assert abs(sg[k] - so[k]) <= 1e-5 * max(1.0, abs(so[k])), (k, sg[k], so[k])
 
 
+@pytest.mark.parametrize("variant", ["fused", "split"])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
-def test_config2_4096x512_random_actions_philox_resets(storage):
+def test_config2_4096x512_random_actions_philox_resets(storage, variant):
     """BASELINE config 2: 4096 envs x 512 steps, U(-1,1) actions keyed by (seed, step, env), in-kernel Philox resets."""
     n, T = 4096, 512
-    env = _batch(n, storage=storage, seed=0)
+    env = _batch(n, storage=storage, seed=0, variant=variant)
     orc = oracle.OracleBatch(n, to_oracle_params(env.params), seed=0, n_threads=8,
                              storage=oracle.STORAGE_F32 if storage == "f32" else oracle.STORAGE_F64)
     np.testing.assert_array_equal(_np(env.reset()), orc.reset())
@@ -131,10 +134,11 @@ def test_config2_4096x512_random_actions_philox_resets(storage):
     assert env.get_stats()["episodes"] > 50_000     # ~5 % of envs end per step (bubble)
 
 
-def test_ragged_sizes_and_masked_reset():
+@pytest.mark.parametrize("variant", ["fused", "split"])
+def test_ragged_sizes_and_masked_reset(variant):
     """N not a multiple of the wave / block size, single env, and reset(mask)."""
-    for n in (1, 63, 65, 257, 1000):
-        env = _batch(n, storage="f32", seed=11)
+    for n in (1, 63, 65, 129, 257, 1000):
+        env = _batch(n, storage="f32", seed=11, variant=variant)
         orc = oracle.OracleBatch(n, to_oracle_params(env.params), seed=11, storage=oracle.STORAGE_F32)
         np.testing.assert_array_equal(_np(env.reset()), orc.reset())
         _compare_run(env, orc, [counter_actions(5, t, n) for t in range(40)], "f32")
@@ -147,11 +151,12 @@ def test_ragged_sizes_and_masked_reset():
 
 
 def test_sharding_is_index_independent():
-    """Env i of a shard with env_id_offset=o behaves exactly as env o+i of the unsharded batch (RNG keyed by global id)."""
+    """Env i of a shard with env_id_offset=o behaves exactly as env o+i of the unsharded batch (RNG keyed by global id),
+    and the two kernel variants give bit-identical outputs."""
     n = 512
-    full = _batch(n, storage="f32", seed=5)
-    lo = _batch(n // 2, storage="f32", seed=5, env_id_offset=0)
-    hi = _batch(n // 2, storage="f32", seed=5, env_id_offset=n // 2)
+    full = _batch(n, storage="f32", seed=5, variant="fused")
+    lo = _batch(n // 2, storage="f32", seed=5, env_id_offset=0, variant="split")
+    hi = _batch(n // 2, storage="f32", seed=5, env_id_offset=n // 2, variant="split")
     o = _np(full.reset())
     np.testing.assert_array_equal(o[: n // 2], _np(lo.reset()))
     np.testing.assert_array_equal(o[n // 2:], _np(hi.reset()))
