@@ -119,7 +119,8 @@ typedef struct RdvStepOut {
   float*   terminal_obs;    /* [N,17] nullable; row i written only where done[i] (SB3 info["terminal_observation"]) */
   float*   episode_return;  /* [N]    nullable; written where done (Monitor info["episode"]["r"]) */
   int32_t* episode_length;  /* [N]    nullable; written where done (Monitor info["episode"]["l"]) */
-  uint8_t* done_reason;     /* [N]    nullable; 0 = not done, 1 obs, 2 time, 3 bubble, 4 attitude (rendezvous_env.py:377) */
+  uint8_t* done_reason;     /* [N]    nullable; bits 0-2: 0 = not done, 1 obs, 2 time, 3 bubble, 4 attitude (rendezvous_env.py:377);
+                                      where done also bit 4 = the episode entered the keep-out zone, bit 5 = it had >= 1 success step */
   double*  diag;            /* [N,8]  nullable; evaluator diagnostics of the post-step (pre-reset) state, RDV_DIAG_DIM */
 } RdvStepOut;
 

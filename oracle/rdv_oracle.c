@@ -527,7 +527,8 @@ static void step_one(const OrcParams* p, const OrcConfig* c, OrcEnv* e, int64_t 
   e->episode_return = canon(e->episode_return + rew, c->storage);
 
   out->reward[i] = rew; out->done[i] = (uint8_t)done;
-  if (out->done_reason) out->done_reason[i] = (uint8_t)reason;
+  if (out->done_reason)   /* reason | collided-in-episode << 4 | succeeded-in-episode << 5 (flag bits only where done) */
+    out->done_reason[i] = (uint8_t)(reason | ((done && e->collided) ? 16 : 0) | ((done && e->success > 0) ? 32 : 0));
   if (out->diag) orc_diagnose(p, e, out->diag + 8 * i);
   loc->done = done; loc->reason = reason;
   if (done) {

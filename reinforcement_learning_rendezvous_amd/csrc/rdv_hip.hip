@@ -201,7 +201,9 @@ __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i,
   if (active) {
     A.reward[i] = r.reward;
     A.done[i] = (uint8_t)r.done;
-    if (A.done_reason) A.done_reason[i] = (uint8_t)r.reason;
+    if (A.done_reason)   // reason | collided-in-episode << 4 | succeeded-in-episode << 5 (the flag bits only where done)
+      A.done_reason[i] = (uint8_t)(r.reason | ((fin && (e.flags & FLAG_COLLIDED)) ? 16 : 0) |
+                                   ((fin && (e.flags >> SUCCESS_SHIFT) != 0u) ? 32 : 0));
   }
   if (fin) {
     if (A.terminal_obs) {

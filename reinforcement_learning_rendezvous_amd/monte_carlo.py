@@ -1,0 +1,195 @@
+"""
+Batched Monte Carlo evaluation — the reference's monte_carlo.py (main :15-91, evaluate :94-207) rewired onto the GPU batch.
+
+The reference evaluates the 1000 stored initial conditions one after the other (56,776 serial env steps + policy
+calls, ~200 s on a CPU core).  Here every initial condition is one env of a halting batch (``on_done="halt"``), the
+policy runs on the whole batch at once, and a trajectory's per-step diagnostics come out of the same fused kernel
+(``step(..., diag=True)``).  The post-processing reproduces the reference's 12 output columns (:192-205).
+
+    python -m reinforcement_learning_rendezvous_amd.monte_carlo --model models/mlp_model_best.zip \
+           --input_file results/data_monte_carlo_initial_conditions.csv --save
+
+The env engine is duck-typed (reset/set_state/observe/diagnose/step/get_aux, tensors in and out); the default and
+only product engine is the HIP-backed RendezvousBatch.
+"""
+import argparse
+import os
+
+import numpy as np
+import torch
+
+from .params import params_from_config
+
+COLUMNS = ["ep_len", "num_collisions", "collided", "total_reward", "total_delta_v", "num_successes", "succeeded",
+           "min_dist_from_koz", "pos_error", "vel_error", "att_error", "rot_error"]          # monte_carlo.py:39-52
+STATE_COLUMNS = ["rcx", "rcy", "rcz", "vcx", "vcy", "vcz", "qcw", "qcx", "qcy", "qcz", "wcx", "wcy", "wcz",
+                 "qtw", "qtx", "qty", "qtz", "wtx", "wty", "wtz"]        # verification/get_initial_conditions.py:29-36
+
+
+def load_initial_conditions(path):
+    """The reference's CSV (header row, leading index column) or an .npz with a [M,20] ``states`` array."""
+    if path.endswith(".npz"):
+        return np.asarray(np.load(path, allow_pickle=False)["states"], dtype=np.float64)
+    with open(path) as f:
+        header = f.readline().strip().split(",")
+    idx = [header.index(c) for c in STATE_COLUMNS]
+    data = np.loadtxt(path, delimiter=",", skiprows=1, dtype=np.float64, ndmin=2)
+    return data[:, idx]
+
+
+def make_eval_params(config=None):
+    """monte_carlo.py:24-27: ``make_env(reward_kwargs=None, config=dict(dt=1, t_max=60), stochastic=False)``."""
+    cfg = dict(dt=1, t_max=60)
+    if config:
+        cfg.update(config)
+    return params_from_config(reward_kwargs=None, config=cfg, stochastic=False)
+
+
+def terminal_errors(errors, max_rd, max_vd, max_qd, max_wd):
+    """monte_carlo.py:153-189 for one trajectory; ``errors`` is [4, L] (valid steps only)."""
+    pos, vel, att, rot = errors
+    pos_mask, vel_mask, att_mask, rot_mask = pos < max_rd, vel < max_vd, att < max_qd, rot < max_wd
+    all_mask = pos_mask & vel_mask & att_mask & rot_mask
+    if np.any(all_mask):
+        index = int(np.argmax(all_mask))
+    else:
+        three_mask = (pos_mask & vel_mask & att_mask) | (pos_mask & vel_mask & rot_mask)
+        if np.any(three_mask):
+            index = int(np.argmax(three_mask))
+        else:
+            two_mask = pos_mask & vel_mask
+            if np.any(two_mask):
+                index = int(np.argmax(two_mask))
+            elif np.any(pos_mask):
+                index = int(np.argmax(pos_mask))
+            else:
+                index = -1
+    return (pos[index:].mean(), vel[index:].mean(), np.degrees(att[index:].mean()), np.degrees(rot[index:].mean()))
+
+
+@torch.no_grad()
+def evaluate_batch(policy, env, initial_states, deterministic=True, generator=None):
+    """monte_carlo.evaluate (:94-207) for every row of ``initial_states`` at once.
+
+    ``env`` must hold ``len(initial_states)`` envs in halt mode; returns a dict of 12 float64 arrays (COLUMNS)."""
+    p = env.params
+    states = np.array(initial_states, dtype=np.float64, copy=True)
+    m = states.shape[0]
+    assert m == env.num_envs, (m, env.num_envs)
+    states[:, 6:10] /= np.linalg.norm(states[:, 6:10], axis=1, keepdims=True)        # :66
+    states[:, 13:17] /= np.linalg.norm(states[:, 13:17], axis=1, keepdims=True)      # :67
+    steps_max = int(p.t_max / p.dt) + 1                                              # :97
+    errors = np.full((m, 4, steps_max + 1), np.nan)
+    env.reset()                                                                      # :106 (flags of the nominal state stay, :107-112)
+    env.set_state(torch.from_numpy(states))
+    obs = env.observe()                                                              # :113
+    d0 = env.diagnose().cpu().numpy()
+    errors[:, :, 0] = d0[:, 0:4]                                                     # :117
+    num_collisions = d0[:, 4].copy()                                                 # :119-120
+    num_successes = d0[:, 5].copy()                                                  # :121-122 (check_success is 0 once collided)
+    min_dist = d0[:, 6].copy()                                                       # :123
+    total_reward = np.zeros(m)
+    length = np.zeros(m, dtype=np.int64)
+    active = np.ones(m, dtype=bool)
+    k = 1
+    while active.any():                                                              # :126
+        if k > steps_max + 1:
+            raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
+        actions = policy.act(obs, deterministic=deterministic, generator=generator)  # :128-133
+        obs, rew, done = env.step(actions.contiguous(), diag=True)                   # :136
+        dg = env.diag.cpu().numpy()
+        rw = rew.cpu().numpy().astype(np.float64)
+        dn = done.cpu().numpy().astype(bool)
+        if k <= steps_max:
+            errors[active, :, k] = dg[active, 0:4]                                   # :140
+        num_collisions[active] += dg[active, 4]                                      # :142-144
+        num_successes[active] += dg[active, 5]                                       # :145-146
+        min_dist[active] = np.minimum(min_dist[active], dg[active, 6])               # :147-149
+        total_reward[active] += rw[active]                                           # :150
+        length[active] = k
+        active &= ~dn
+        k += 1
+    aux = env.get_aux().cpu().numpy()
+    out = {c: np.zeros(m) for c in COLUMNS}
+    out["ep_len"] = np.round(length * p.dt, 3)                                       # t[0,-1] with :193's rounding
+    out["num_collisions"] = num_collisions
+    out["collided"] = (num_collisions > 0).astype(np.float64)
+    out["total_reward"] = total_reward
+    out["total_delta_v"] = aux[:, 4]
+    out["num_successes"] = num_successes
+    out["succeeded"] = (num_successes > 0).astype(np.float64)
+    out["min_dist_from_koz"] = min_dist
+    for i in range(m):
+        e = errors[i, :, : length[i] + 1]
+        (out["pos_error"][i], out["vel_error"][i], out["att_error"][i], out["rot_error"][i]) = terminal_errors(
+            e, p.max_rd_error, p.max_vd_error, p.max_qd_error, p.max_wd_error)
+    return out
+
+
+def run(policy, initial_states, device="cuda:0", storage="f32", config=None, deterministic=True, seed=0,
+        engine_factory=None):
+    """Evaluate all rows on one device.  ``engine_factory(num_envs, params)`` overrides the HIP engine (tests only)."""
+    params = make_eval_params(config)
+    m = len(initial_states)
+    if engine_factory is None:
+        from .batch import RendezvousBatch
+        env = RendezvousBatch(m, params=params, device=device, storage=storage, on_done="halt", seed=seed)
+        policy = policy.to(env.device)
+        gen = None if deterministic else torch.Generator(device=env.device).manual_seed(seed)
+    else:
+        env = engine_factory(m, params)
+        gen = None if deterministic else torch.Generator().manual_seed(seed)
+    out = evaluate_batch(policy, env, initial_states, deterministic=deterministic, generator=gen)
+    if hasattr(env, "close"):
+        env.close()
+    return out
+
+
+def summary(results):
+    m = len(results["succeeded"])
+    return dict(trajectories=m, success_percent=float(results["succeeded"].sum() / m * 100),     # :75-78
+                collision_percent=float(results["collided"].sum() / m * 100))
+
+
+def save_csv(results, directory="."):
+    """monte_carlo.py:81-90: ``monte_carlo_resultsNN.csv``, first free NN, index column + the 12 columns."""
+    num = 0
+    while os.path.exists(os.path.join(directory, f"monte_carlo_results{str(num).zfill(2)}.csv")):
+        num += 1
+    path = os.path.join(directory, f"monte_carlo_results{str(num).zfill(2)}.csv")
+    m = len(results[COLUMNS[0]])
+    with open(path, "w") as f:
+        f.write("," + ",".join(COLUMNS) + "\n")
+        for i in range(m):
+            f.write(str(i) + "," + ",".join(repr(float(results[c][i])) for c in COLUMNS) + "\n")
+    return path
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description="Batched Monte Carlo evaluation on MI355X (reference: monte_carlo.py)")
+    ap.add_argument("--model", required=True, help="SB3 checkpoint zip (policy.pth inside) or an .npz of its weights")
+    ap.add_argument("--input_file", required=True, help="CSV of initial conditions (reference schema) or .npz")
+    ap.add_argument("--save", action="store_true")                                   # arguments.py:101-126
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--storage", choices=["f32", "f64"], default="f32")
+    ap.add_argument("--stochastic", action="store_true", help="sample actions (mean + std*N) instead of the mean")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args(argv)
+    from .policy import MlpPolicy
+    policy = MlpPolicy.from_npz(args.model) if args.model.endswith(".npz") else MlpPolicy.from_sb3_zip(args.model)
+    if not os.path.exists(args.input_file):
+        raise SystemExit(f"Could not find the requested file named '{args.input_file}'")   # :35-38
+    ics = load_initial_conditions(args.input_file)
+    if not args.save:
+        print("Results will NOT be saved. Use the '--save' argument to save the results as a csv file.")   # :17-18
+    res = run(policy, ics, device=args.device, storage=args.storage, deterministic=not args.stochastic, seed=args.seed)
+    s = summary(res)
+    print(f"Success %: {s['success_percent']}")
+    print(f"Collision%: {s['collision_percent']}")
+    if args.save:
+        print(f"Saving results to '{save_csv(res)}'... Done")
+    return res
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,214 @@
+"""
+RendezvousVecEnv — the SB3 ``VecEnv`` surface over N GPU-resident rendezvous environments.
+
+It replaces ``DummyVecEnv([lambda: Monitor(RendezvousEnv(...))])`` (reference main.py:33-34, utils/general.py:55-56):
+same spaces (rendezvous_env.py:133-144), NumPy in / NumPy out, auto-reset on done with
+``infos[i]["terminal_observation"]`` and a Monitor-style ``infos[i]["episode"] = {"r", "l", "t"}``; as in the reference,
+``TimeLimit.truncated`` is never set.  If stable_baselines3 is importable the class derives from its ``VecEnv`` so that
+``PPO("MlpPolicy", RendezvousVecEnv(...))`` type-checks; without it the same methods are provided duck-typed.
+The tensor-native fast path (no host copies) is the underlying ``RendezvousBatch`` (``.batch``).
+"""
+import time
+
+import numpy as np
+import torch
+
+from .params import FIELD_NAMES, make_params
+
+try:  # SB3 1.6.x (the version the reference pins); absent in this image
+    from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase
+    _HAVE_SB3 = True
+except Exception:  # pragma: no cover - depends on the environment
+    _VecEnvBase = object
+    _HAVE_SB3 = False
+
+try:
+    from gym import spaces as _spaces
+except Exception:  # pragma: no cover
+    try:
+        from gymnasium import spaces as _spaces
+    except Exception:
+        _spaces = None
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box when gym is absent (gym 0.21 semantics of `contains`)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.dtype = np.dtype(dtype)
+        self.shape = tuple(shape)
+        self.low = np.full(self.shape, low, dtype=self.dtype)
+        self.high = np.full(self.shape, high, dtype=self.dtype)
+        self._rng = np.random.default_rng()
+
+    def contains(self, x):
+        x = np.asarray(x)
+        return bool(np.can_cast(x.dtype, self.dtype) and x.shape == self.shape
+                    and np.all(x >= self.low) and np.all(x <= self.high))
+
+    def sample(self):
+        return self._rng.uniform(self.low, self.high).astype(self.dtype)
+
+    def seed(self, seed=None):
+        self._rng = np.random.default_rng(seed)
+
+    def __repr__(self):
+        return f"Box({self.low.min()}, {self.high.max()}, {self.shape}, {self.dtype})"
+
+
+def _box(low, high, shape):
+    if _spaces is not None:
+        return _spaces.Box(low=low, high=high, shape=shape, dtype=np.float32)
+    return Box(low, high, shape)
+
+
+_END_REASONS = ["", "obs", "time", "bubble", "attitude"]          # rendezvous_env.py:377
+_STATE_ATTRS = {"rc": slice(0, 3), "vc": slice(3, 6), "qc": slice(6, 10), "wc": slice(10, 13), "qt": slice(13, 17),
+                "wt": slice(17, 20)}
+_AUX_ATTRS = {"t": 0, "bubble_radius": 1, "collided": 2, "success": 3, "total_delta_v": 4, "total_delta_w": 5}
+_DIAG_METHODS = {"get_errors": slice(0, 4), "get_attitude_error": 2, "check_collision": 4, "check_success": 5,
+                 "dist_from_koz": 6}
+
+
+class RendezvousVecEnv(_VecEnvBase):
+    def __init__(self, num_envs, device="cuda:0", storage="f32", seed=0, quiet=True, params=None, engine=None,
+                 **env_kwargs):
+        """``env_kwargs``: the reference constructor's keyword arguments (rendezvous_env.py:17-37), shared by all envs.
+        ``engine``: an already constructed batch (tests inject a CPU-oracle-backed one; the product default is HIP)."""
+        if engine is None:
+            from .batch import RendezvousBatch
+            p = params if params is not None else make_params(**env_kwargs)
+            engine = RendezvousBatch(num_envs, params=p, device=device, storage=storage, on_done="reset", seed=seed)
+        self.batch = engine
+        self.quiet = quiet
+        obs_space, act_space = _box(-1, 1, (17,)), _box(-1, 1, (6,))                 # :133-144
+        if _HAVE_SB3:
+            super().__init__(engine.num_envs, obs_space, act_space)
+        else:
+            self.num_envs, self.observation_space, self.action_space = engine.num_envs, obs_space, act_space
+        self.metadata = {"render.modes": []}
+        self._actions = None
+        self._infos = [{} for _ in range(self.num_envs)]
+        self._dirty = []
+        self._t_start = time.time()
+        pin = torch.cuda.is_available() and engine.device.type == "cuda"
+        self._act_host = torch.zeros((self.num_envs, 6), dtype=torch.float32, pin_memory=pin)
+
+    # ------------------------------------------------------------------------------------------------ VecEnv API
+    def reset(self):
+        return self.batch.reset().cpu().numpy()
+
+    def step_async(self, actions):
+        a = np.asarray(actions, dtype=np.float32)
+        assert a.shape == (self.num_envs, 6), f"expected actions of shape ({self.num_envs}, 6), got {a.shape}"   # :168
+        self._act_host.copy_(torch.from_numpy(a))
+        self._actions = self._act_host.to(self.batch.device, non_blocking=True)
+
+    def step_wait(self):
+        b = self.batch
+        obs, rew, done = b.step(self._actions)
+        obs_h, rew_h = obs.cpu().numpy(), rew.cpu().numpy()
+        done_h = done.cpu().numpy().astype(bool)
+        for i in self._dirty:           # only the entries written last step are touched: O(#done), not O(N)
+            self._infos[i] = {}
+        self._dirty = []
+        idx = np.flatnonzero(done_h)
+        if idx.size:
+            t_obs = b.terminal_obs.cpu().numpy()
+            ep_r, ep_l = b.episode_return.cpu().numpy(), b.episode_length.cpu().numpy()
+            reason = b.done_reason.cpu().numpy()
+            now = round(time.time() - self._t_start, 6)
+            for i in idx:
+                code = int(reason[i])
+                self._infos[i] = {
+                    "terminal_observation": t_obs[i].copy(),
+                    "episode": {"r": float(ep_r[i]), "l": int(ep_l[i]), "t": now},      # SB3 Monitor
+                    "end_reason": _END_REASONS[code & 7], "collided": bool(code & 16), "success": bool(code & 32),
+                }
+                if not self.quiet:                                                       # :376-382
+                    dist = float(np.linalg.norm(t_obs[i][0:3]) * b.params.max_axial_distance)
+                    print("Episode end | r = " + str(round(dist, 2)).rjust(5) + " | t = " +
+                          str(round(int(ep_l[i]) * b.params.dt, 3)).rjust(4) + " | " + _END_REASONS[code & 7].center(8) +
+                          " | " + ("Collided" if code & 16 else " "))
+            self._dirty = idx.tolist()
+        return obs_h, rew_h, done_h, self._infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def close(self):
+        self.batch.close()
+
+    def seed(self, seed=None):
+        self.batch.seed(0 if seed is None else int(seed))
+        return [seed] * self.num_envs
+
+    def render(self, mode="human"):      # :272-279 no-op
+        return None
+
+    def get_images(self):
+        return []
+
+    # ------------------------------------------------------------------------------------------------ attribute access
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, int):
+            return [indices]
+        return list(indices)
+
+    def get_attr(self, attr_name, indices=None):
+        """Per-env attributes of RendezvousEnv: state (rc..wt), bookkeeping (t, collided, success, ...), parameters."""
+        idx = self._indices(indices)
+        if attr_name in _STATE_ATTRS:
+            s = self.batch.get_state().cpu().numpy()
+            return [s[i, _STATE_ATTRS[attr_name]].copy() for i in idx]
+        if attr_name in _AUX_ATTRS:
+            a = self.batch.get_aux().cpu().numpy()
+            col = a[:, _AUX_ATTRS[attr_name]]
+            cast = bool if attr_name == "collided" else (int if attr_name == "success" else float)
+            return [cast(col[i]) for i in idx]
+        if attr_name in FIELD_NAMES:
+            v = self.batch.params.to_dict()[attr_name]
+            return [np.array(v) if isinstance(v, list) else v for _ in idx]
+        if attr_name == "reward_kwargs":
+            p = self.batch.params
+            return [dict(collision_coef=p.collision_coef, bonus_coef=p.bonus_coef, fuel_coef=p.fuel_coef,
+                         att_coef=p.att_coef) for _ in idx]
+        if attr_name in ("observation_space", "action_space", "quiet"):
+            return [getattr(self, attr_name) for _ in idx]
+        raise AttributeError(f"RendezvousVecEnv has no per-env attribute '{attr_name}'")
+
+    def set_attr(self, attr_name, value, indices=None):
+        """Parameters are shared by the batch (one kernel-argument block); state goes through ``batch.set_state``."""
+        if attr_name == "reward_kwargs":
+            self.batch.set_reward_kwargs(**value)
+        elif attr_name in FIELD_NAMES:
+            p = self.batch.params.copy()
+            p.update(**{attr_name: value})
+            self.batch.set_params(p)
+        elif attr_name == "quiet":
+            self.quiet = bool(value)
+        else:
+            raise AttributeError(f"cannot set '{attr_name}' on RendezvousVecEnv")
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        """The helper methods the reference's evaluators call after each step (custom_callbacks.py:211-253)."""
+        idx = self._indices(indices)
+        if method_name in _DIAG_METHODS:
+            d = self.batch.diagnose().cpu().numpy()
+            sel = _DIAG_METHODS[method_name]
+            if method_name in ("check_collision",):
+                return [bool(d[i, sel]) for i in idx]
+            if method_name == "check_success":
+                return [int(d[i, sel]) for i in idx]
+            return [d[i, sel].copy() if isinstance(sel, slice) else float(d[i, sel]) for i in idx]
+        if method_name == "get_observation":
+            o = self.batch.observe().cpu().numpy()
+            return [o[i].copy() for i in idx]
+        raise AttributeError(f"RendezvousVecEnv does not implement env_method('{method_name}')")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        # no Monitor object exists, but its episode statistics are reported in infos[i]["episode"]
+        return [False for _ in self._indices(indices)]

@@ -32,8 +32,9 @@ def counter_actions(seed, step, n, lo=0):
     """U(-1,1) float32 actions keyed by (seed, step, env id): reproducible on any host, any shard."""
     ids = np.arange(lo, lo + n, dtype=np.uint64)
     out = np.empty((n, 6), np.float32)
+    key = np.uint64((int(seed) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF)
     for j in range(6):
-        x = (ids * np.uint64(6) + np.uint64(j)) ^ (np.uint64(step) << np.uint64(32)) ^ (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15))
+        x = (ids * np.uint64(6) + np.uint64(j)) ^ (np.uint64(step) << np.uint64(32)) ^ key
         # splitmix64 finaliser
         x = (x + np.uint64(0x9E3779B97F4A7C15))
         x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)

@@ -1,0 +1,128 @@
+"""
+CPU-side checks of the drop-in boundary: librdv_hip.so loads without a GPU, exports every symbol include/rdv.h declares,
+its host-only entry points work, and the product path fails loudly (no CPU fallback) when there is no device.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+from reinforcement_learning_rendezvous_amd import _native as N
+from reinforcement_learning_rendezvous_amd.params import EnvParams, make_params, params_from_config
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_library_is_built_and_loads():
+    N.build()
+    assert os.path.exists(N.LIB_PATH)
+    assert N.lib().rdv_version() == 1
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, "include", "rdv.h")).read()
+    declared = sorted(set(re.findall(r"\b(rdv_[a-z_]+)\s*\(", header)))
+    assert declared == sorted(N.SYMBOLS), (declared, sorted(N.SYMBOLS))
+    lib = N.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    nm = subprocess.run(["nm", "-D", "--defined-only", N.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (rdv_[a-z_]+)", nm))
+    assert exported == set(declared)        # nothing undeclared leaks out, nothing declared is missing
+    assert "orc_" not in nm                  # the oracle is not linked into the product
+
+
+def test_params_struct_layouts_agree():
+    assert C.sizeof(EnvParams) == 57 * 8
+    assert C.sizeof(oracle.OrcParams) == C.sizeof(EnvParams)
+    assert oracle.lib().orc_sizeof_params() == C.sizeof(EnvParams)
+    assert [n for n, _ in EnvParams._fields_] == [n for n, _ in oracle.OrcParams._fields_]
+
+
+def test_params_default_matches_reference_constructor():
+    p = EnvParams()
+    N.check(N.lib().rdv_params_default(C.byref(p)))
+    q = make_params()
+    for name, _ in EnvParams._fields_:
+        np.testing.assert_allclose(np.asarray(p.to_dict()[name]), np.asarray(q.to_dict()[name]), rtol=1e-15, atol=0, err_msg=name)
+    assert q.max_delta_v == 0.05 and q.bubble_min == 3.0 and q.max_axial_distance == 20.0     # SURVEY §8 constants
+    assert q.n == pytest.approx(1.039679077e-3, rel=1e-9)
+
+
+def test_params_validate_reference_asserts():
+    lib = N.lib()
+    p = make_params()
+    assert lib.rdv_params_validate(C.byref(p)) == 0
+    bad = p.copy()
+    bad.koz_radius = 1.5                       # rendezvous_env.py:155
+    assert lib.rdv_params_validate(C.byref(bad)) == -6
+    assert b"terminal position lies outside corridor" in lib.rdv_last_error()
+    bad = p.copy()
+    bad.max_rd_error = 2.5                     # :156
+    assert lib.rdv_params_validate(C.byref(bad)) == -6
+    bad = p.copy()
+    bad.dt = float("nan")
+    assert lib.rdv_params_validate(C.byref(bad)) == -6
+    with pytest.raises(AssertionError):
+        make_params(koz_radius=1.5)
+    with pytest.raises(AssertionError):
+        make_params(rc0=np.zeros(4))           # :148
+
+
+def test_make_env_config_surface():
+    """utils/environment_utils.make_env (:9-63): scalar rc0 -> [0,-rc0,0], scalar wt0 -> [0,0,wt0], stochastic=False."""
+    p = params_from_config(reward_kwargs=dict(collision_coef=1.0, bonus_coef=2.0), stochastic=False,
+                           config=dict(rc0=15, wt0=0.02, dt=0.5, t_max=60, koz_radius=4, h=400e3))
+    assert list(p.nominal_rc0) == [0.0, -15.0, 0.0] and list(p.nominal_wt0) == [0.0, 0.0, 0.02]
+    assert p.rc0_range == p.vc0_range == p.qc0_range == p.wc0_range == p.qt0_range == p.wt0_range == 0.0
+    assert p.max_axial_distance == 25.0 and p.bubble_radius0 == 25.0 and p.bubble_decrease_rate == 0.25
+    assert p.collision_coef == 1.0 and p.bonus_coef == 2.0 and p.fuel_coef == 0.2 and p.att_coef == 1
+    assert p.n == pytest.approx(np.sqrt(3.986004418e14 / (6371e3 + 400e3) ** 3))
+    with pytest.raises(TypeError):
+        params_from_config(reward_kwargs=dict(nonsense=1))
+
+
+def test_workspace_bytes_is_host_only():
+    lib = N.lib()
+    n = 65536
+    b32, b64 = lib.rdv_workspace_bytes(n, 0), lib.rdv_workspace_bytes(n, 1)
+    assert b32 >= 7 * n * 16 and b64 >= 7 * n * 32 and b64 > b32
+    assert lib.rdv_workspace_bytes(0, 0) == -1 and lib.rdv_workspace_bytes(8, 7) == -1
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the no-device behaviour")
+def test_create_fails_loudly_without_a_gpu():
+    lib = N.lib()
+    h = C.c_void_p()
+    p = make_params()
+    rc = lib.rdv_create(C.byref(p), 16, 0, 0, 0, 0, 0, None, C.byref(h))
+    assert rc == -2 and b"no CPU path" in lib.rdv_last_error()
+    assert lib.rdv_step(None, None, None, None) == -5          # bad handle, not a crash
+    from reinforcement_learning_rendezvous_amd import RdvError
+    from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+    with pytest.raises(RdvError):
+        RendezvousBatch(16, device="cuda:0")
+    with pytest.raises(RdvError):
+        RendezvousBatch(16, device="cpu")
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
+                assert "librdv_oracle" not in text and "rdv_oracle.h" not in text, f

@@ -59,7 +59,7 @@ def test_golden_transitions_fp64_storage(name, variant):
         o, r, d = _np(o), _np(r), _np(d).astype(bool)
         gd = g["done"][t].astype(bool)
         np.testing.assert_array_equal(d[v], gd[v], err_msg=f"done, step {t}")
-        np.testing.assert_array_equal(_np(env.done_reason)[v], g["reason"][t][v], err_msg=f"reason, step {t}")
+        np.testing.assert_array_equal(_np(env.done_reason)[v] & 7, g["reason"][t][v], err_msg=f"reason, step {t}")
         np.testing.assert_allclose(r[v], g["reward"][t][v].astype(np.float32), rtol=2e-7, atol=2e-7)
         np.testing.assert_allclose(o[v], g["obs_ret"][t][v], rtol=0, atol=1.2e-7, err_msg=f"obs, step {t}")
         dg = _np(env.diag)

@@ -1,0 +1,217 @@
+"""
+CPU tests of the product's host logic above the C ABI — VecEnv surface, Monte Carlo post-processing, policy, and the
+N>1 sharding path (world_size-2 gloo) — with the CPU oracle injected as the engine (tests may use the oracle; the
+product never does).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, counter_actions, load_golden
+from oracle_engine import OracleEngine
+from reinforcement_learning_rendezvous_amd import monte_carlo as mc
+from reinforcement_learning_rendezvous_amd.params import make_params
+from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+from reinforcement_learning_rendezvous_amd.sharding import shard_range
+from reinforcement_learning_rendezvous_amd.vec_env import RendezvousVecEnv
+
+
+def _vec(n, **kw):
+    p = make_params(**kw)
+    return RendezvousVecEnv(n, engine=OracleEngine(n, p, storage="f32", seed=4), quiet=True)
+
+
+def test_vecenv_spaces_and_shapes():
+    """What stable_baselines3.common.env_checker.check_env verifies for the reference env (rendezvous_env.py:607-614)."""
+    env = _vec(8)
+    assert env.num_envs == 8
+    assert env.observation_space.shape == (17,) and env.action_space.shape == (6,)
+    assert env.observation_space.dtype == np.float32
+    obs = env.reset()
+    assert obs.shape == (8, 17) and obs.dtype == np.float32
+    assert all(env.observation_space.contains(o) for o in obs)
+    obs, rew, done, infos = env.step(np.zeros((8, 6), np.float32))
+    assert obs.shape == (8, 17) and rew.shape == (8,) and rew.dtype == np.float32 and done.dtype == bool
+    assert isinstance(infos, list) and len(infos) == 8 and all(isinstance(i, dict) for i in infos)
+    with pytest.raises(AssertionError):
+        env.step(np.zeros((8, 5), np.float32))          # reference: assert action.shape == (6,) (:168)
+
+
+def test_vecenv_autoreset_terminal_observation_and_monitor_info():
+    n = 64
+    env = _vec(n)
+    twin = OracleEngine(n, make_params(), storage="f32", seed=4)      # same engine stepped without the VecEnv layer
+    np.testing.assert_array_equal(env.reset(), twin.reset().numpy())
+    returns = np.zeros(n)
+    n_done = 0
+    for t in range(60):
+        a = counter_actions(9, t, n)
+        obs, rew, done, infos = env.step(a)
+        o2, r2, d2 = twin.step(torch.from_numpy(a))
+        np.testing.assert_array_equal(obs, o2.numpy())
+        np.testing.assert_array_equal(done, d2.numpy().astype(bool))
+        returns += rew
+        for i in range(n):
+            if done[i]:
+                n_done += 1
+                info = infos[i]
+                np.testing.assert_array_equal(info["terminal_observation"], twin.terminal_obs[i].numpy())
+                assert info["terminal_observation"].shape == (17,)
+                assert not np.array_equal(info["terminal_observation"], obs[i])       # obs[i] is the reset observation
+                assert info["episode"]["l"] == int(twin.episode_length[i]) > 0
+                assert info["episode"]["r"] == pytest.approx(returns[i], rel=1e-4, abs=1e-4)
+                assert info["end_reason"] in ("obs", "time", "bubble", "attitude")
+                assert "TimeLimit.truncated" not in info                                # reference never sets it
+                returns[i] = 0.0
+            else:
+                assert infos[i] == {}
+    assert n_done > 20
+
+
+def test_vecenv_attribute_access_mirrors_the_reference_env():
+    env = _vec(4, dt=0.5, t_max=30, koz_radius=4.0, reward_kwargs=dict(bonus_coef=3.0))
+    env.reset()
+    assert env.get_attr("dt") == [0.5] * 4 and env.get_attr("t_max", indices=[1]) == [30.0]
+    assert env.get_attr("koz_radius", 0) == [4.0]
+    assert env.get_attr("reward_kwargs")[0]["bonus_coef"] == 3.0
+    rc = env.get_attr("rc")
+    assert len(rc) == 4 and rc[0].shape == (3,) and abs(rc[0][1] + 10) < 1.1
+    assert env.get_attr("t") == [0.0] * 4 and env.get_attr("collided") == [False] * 4
+    env.step(np.zeros((4, 6), np.float32))
+    assert env.get_attr("t") == [0.5] * 4
+    errs = env.env_method("get_errors")
+    assert len(errs) == 4 and errs[0].shape == (4,)
+    assert env.env_method("check_collision") == [False] * 4
+    assert isinstance(env.env_method("dist_from_koz", indices=2)[0], float)
+    env.set_attr("reward_kwargs", dict(fuel_coef=0.0, att_coef=0.0, collision_coef=0.0))
+    _, rew, _, _ = env.step(np.ones((4, 6), np.float32))
+    np.testing.assert_array_equal(rew, 0.0)               # only the attitude and fuel terms act far from the target
+    assert env.env_is_wrapped(object) == [False] * 4
+    with pytest.raises(AttributeError):
+        env.get_attr("no_such_attribute")
+
+
+def test_policy_matches_numpy_forward_and_sb3_signature():
+    w = np.load(os.path.join(GOLDEN, "mlp_policy.npz"))
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    rng = np.random.default_rng(0)
+    obs = rng.uniform(-1, 1, (32, 17)).astype(np.float32)
+    h = np.tanh(obs @ w["mlp_extractor.policy_net.0.weight"].T + w["mlp_extractor.policy_net.0.bias"])
+    h = np.tanh(h @ w["mlp_extractor.policy_net.2.weight"].T + w["mlp_extractor.policy_net.2.bias"])
+    ref = np.clip(h @ w["action_net.weight"].T + w["action_net.bias"], -1, 1)
+    act, state = pol.predict(obs, deterministic=True)
+    assert state is None and act.shape == (32, 6) and act.dtype == np.float32
+    np.testing.assert_allclose(act, ref, rtol=0, atol=2e-6)
+    a1 = pol.act(torch.from_numpy(obs), deterministic=False, generator=torch.Generator().manual_seed(1))
+    a2 = pol.act(torch.from_numpy(obs), deterministic=False, generator=torch.Generator().manual_seed(1))
+    assert torch.equal(a1, a2) and float(a1.abs().max()) <= 1.0
+    assert float((a1 - torch.from_numpy(act)).abs().mean()) > 1e-3
+    assert MlpPolicy().mean(torch.zeros(2, 17)).shape == (2, 6)      # random-init architecture (bench fallback)
+
+
+def test_terminal_error_index_logic():
+    """monte_carlo.py:153-189: first index where all four (else three, two, one) error masks hold; else the last step."""
+    lim = (0.5, 0.1, np.radians(5), np.radians(1))
+    L = 6
+    big = np.array([[1.0] * L, [1.0] * L, [1.0] * L, [1.0] * L])
+    e = big.copy()
+    out = mc.terminal_errors(e, *lim)
+    assert out[0] == pytest.approx(1.0) and out[2] == pytest.approx(np.degrees(1.0))       # index -1: last sample only
+    e = big.copy(); e[0, 3:] = 0.2                      # only pos satisfied from step 3
+    assert mc.terminal_errors(e, *lim)[0] == pytest.approx(0.2)
+    e = big.copy(); e[0, 2:] = 0.2; e[1, 4:] = 0.05     # pos & vel from step 4
+    o = mc.terminal_errors(e, *lim)
+    assert o[0] == pytest.approx(0.2) and o[1] == pytest.approx(0.05)
+    e = big.copy(); e[0, 1:] = 0.2; e[1, 1:] = 0.05; e[3, 5:] = 0.001; e[2, 2:] = 0.01       # three (att) from 2, all from 5
+    o = mc.terminal_errors(e, *lim)
+    assert o[3] == pytest.approx(np.degrees(0.001))     # all-mask wins: mean from index 5
+
+
+def test_initial_conditions_loader_roundtrip(tmp_path):
+    ics = load_golden("mc_initial_conditions.npz")["states"][:5]
+    path = tmp_path / "ics.csv"
+    with open(path, "w") as f:
+        f.write("," + ",".join(mc.STATE_COLUMNS) + "\n")
+        for i, row in enumerate(ics):
+            f.write(str(i) + "," + ",".join(repr(float(x)) for x in row) + "\n")
+    np.testing.assert_array_equal(mc.load_initial_conditions(str(path)), ics)
+    res = {c: np.arange(3, dtype=float) for c in mc.COLUMNS}
+    out = mc.save_csv(res, str(tmp_path))
+    assert os.path.basename(out) == "monte_carlo_results00.csv"
+    assert os.path.basename(mc.save_csv(res, str(tmp_path))) == "monte_carlo_results01.csv"     # :83-87 first free name
+    assert open(out).readline().strip() == "," + ",".join(mc.COLUMNS)
+
+
+def test_shard_ranges_partition_the_index_space():
+    for n, w in ((524288, 8), (1000, 8), (7, 3), (5, 8)):
+        spans = [shard_range(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_range(524288, 3, 8) == (196608, 262144)
+
+
+# ---------------------------------------------------------------------------------------------- world_size 2, gloo
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, n_global, steps, q):
+    import torch.distributed as dist
+    from reinforcement_learning_rendezvous_amd import sharding
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    p = make_params()
+    env, (lo, hi) = sharding.make_shard(n_global, engine_cls=lambda n, env_id_offset: OracleEngine(
+        n, p, storage="f32", seed=21, env_id_offset=env_id_offset))
+    obs = env.reset()
+    trace = []
+    for t in range(steps):
+        a = torch.from_numpy(counter_actions(3, t, n_global)[lo:hi])        # actions keyed by GLOBAL env id
+        obs, rew, done = env.step(a)
+        g = sharding.gather_rollout([obs, rew, done.to(torch.uint8)])
+        if rank == 0:
+            trace.append([x.numpy().copy() for x in g])
+    total = sharding.reduce_stats(env.get_stats())
+    cols = sharding.gather_columns({"lo": np.full(hi - lo, lo), "ret": env.get_aux()[:, 6].numpy()})
+    if rank == 0:
+        q.put((trace, total, cols))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_equals_single_process():
+    import torch.multiprocessing as tmp
+    n, steps, world = 96, 48, 2
+    ctx = tmp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    trace, total, cols = q.get()
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    single = OracleEngine(n, make_params(), storage="f32", seed=21)
+    single.reset()
+    for t in range(steps):
+        o, r, d = single.step(torch.from_numpy(counter_actions(3, t, n)))
+        np.testing.assert_array_equal(trace[t][0], o.numpy(), err_msg=f"obs, step {t}")
+        np.testing.assert_array_equal(trace[t][1], r.numpy())
+        np.testing.assert_array_equal(trace[t][2], d.numpy())
+    ref = single.get_stats()
+    for k in ("env_steps", "episodes", "successes", "collisions", "reasons"):
+        assert total[k] == ref[k], k
+    assert total["sum_return"] == pytest.approx(ref["sum_return"], rel=1e-12)
+    assert ref["episodes"] > 50
+    np.testing.assert_array_equal(cols["lo"], np.repeat([0, 48], 48))
+    np.testing.assert_allclose(cols["ret"], single.get_aux()[:, 6].numpy(), rtol=0, atol=0)
