@@ -57,7 +57,15 @@ def cpu_baseline(n, seconds):
     import numpy as np
     import oracle
     from tests.helpers import counter_actions
-    cores = len(os.sched_getaffinity(0))
+    # threads actually used: the host share of one GPU (16 cores on the bench pool), never more than the affinity
+    # mask or the cgroup CPU quota allow — oversubscribing OpenMP beyond the quota makes the sample meaningless
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("RDV_CPU_THREADS", "16")))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
     acts = [counter_actions(1, t, n) for t in range(RING)]
 
     def run(n_envs, threads, budget, min_steps):

@@ -41,9 +41,9 @@ struct DevParams {
   float  fuel_scale_f32;                // float32(dt * fuel_coef)  (:333)
   float  fuel_div_f32;                  // float32(3 * max_delta_v) (:333)
   int32_t k_time;                       // first step count k with round(k*dt, 3) >= t_max (:193, :368)
-  double obs_lo_r, obs_scale_r;         // normalize_value (general.py:243): (val - lo) * (2/(hi-lo)) - 1
-  double obs_lo_v, obs_scale_v;
-  double obs_lo_w, obs_scale_w;
+  double obs_lo_r, obs_span_r, obs_inv_span_r;   // normalize_value (general.py:243): low, high-low, RN(1/(high-low))
+  double obs_lo_v, obs_span_v, obs_inv_span_v;
+  double obs_lo_w, obs_span_w, obs_inv_span_w;
   double koz_radius, corridor_half_angle;
   double inv_max_attitude_error, inv_max_rd_error, inv_max_qd_error;
   double corridor_axis[3], capture_axis[3], rd[3];
@@ -240,16 +240,26 @@ __device__ __forceinline__ double dist_from_koz(const DevParams& P, const Derive
   return out;
 }
 
-// get_observation (:294-311) with normalize_value (general.py:243): (b-a)*(val-low)/(high-low)+a, a=-1, b=1
+// normalize_value (general.py:243): (b-a)*(val-low)/(high-low)+a with a=-1, b=1.  The quotient is the correctly rounded
+// y/span without a division: q = y*RN(1/span), one fma for the exact residual, one to apply it (Markstein), so the
+// float32 observation is bit-identical to the reference's for an identical state.
+__device__ __forceinline__ float normalized(double val, double lo, double span, double inv_span) {
+#pragma clang fp contract(off)
+  const double y = 2.0 * (val - lo);
+  double q = y * inv_span;
+  q = fma(fma(-q, span, y), inv_span, q);
+  return (float)(q + -1.0);
+}
+// get_observation (:294-311)
 __device__ __forceinline__ void observation(const DevParams& P, const Env& e, float* o) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[i] = (float)fma(e.rc[i] - P.obs_lo_r, P.obs_scale_r, -1.0);
+  for (int i = 0; i < 3; ++i) o[i] = normalized(e.rc[i], P.obs_lo_r, P.obs_span_r, P.obs_inv_span_r);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[3 + i] = (float)fma(e.vc[i] - P.obs_lo_v, P.obs_scale_v, -1.0);
+  for (int i = 0; i < 3; ++i) o[3 + i] = normalized(e.vc[i], P.obs_lo_v, P.obs_span_v, P.obs_inv_span_v);
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[6 + i] = (float)e.qc[i];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[10 + i] = (float)fma(e.wc[i] - P.obs_lo_w, P.obs_scale_w, -1.0);
+  for (int i = 0; i < 3; ++i) o[10 + i] = normalized(e.wc[i], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[13 + i] = (float)e.qt[i];
 }

@@ -533,9 +533,9 @@ static void derive_params(const RdvParams& p, DevParams& d) {
     while (k < 2147483647LL && std::rint((double)k * p.dt * 1e3) / 1e3 < p.t_max) ++k;
     d.k_time = (int32_t)k;
   }
-  d.obs_lo_r = -p.max_axial_distance; d.obs_scale_r = 2.0 / (p.max_axial_distance - (-p.max_axial_distance));
-  d.obs_lo_v = -p.max_axial_speed;    d.obs_scale_v = 2.0 / (p.max_axial_speed - (-p.max_axial_speed));
-  d.obs_lo_w = -p.max_wc;             d.obs_scale_w = 2.0 / (p.max_wc - (-p.max_wc));
+  d.obs_lo_r = -p.max_axial_distance; d.obs_span_r = p.max_axial_distance - (-p.max_axial_distance); d.obs_inv_span_r = 1.0 / d.obs_span_r;
+  d.obs_lo_v = -p.max_axial_speed;    d.obs_span_v = p.max_axial_speed - (-p.max_axial_speed);       d.obs_inv_span_v = 1.0 / d.obs_span_v;
+  d.obs_lo_w = -p.max_wc;             d.obs_span_w = p.max_wc - (-p.max_wc);                         d.obs_inv_span_w = 1.0 / d.obs_span_w;
   d.koz_radius = p.koz_radius; d.corridor_half_angle = p.corridor_half_angle;
   d.inv_max_attitude_error = 1.0 / p.max_attitude_error; d.inv_max_rd_error = 1.0 / p.max_rd_error; d.inv_max_qd_error = 1.0 / p.max_qd_error;
   for (int i = 0; i < 3; ++i) { d.corridor_axis[i] = p.corridor_axis[i]; d.capture_axis[i] = p.capture_axis[i]; d.rd[i] = p.rd[i]; }

@@ -59,7 +59,7 @@ def test_monte_carlo_fp32_storage_flip_budget_and_oracle_agreement():
     env.reset(); orc.reset()
     env.set_state(torch.from_numpy(s)); orc.set_state(torch.from_numpy(s))
     obs = env.observe()
-    np.testing.assert_array_equal(obs.cpu().numpy(), orc.observe().numpy())
+    np.testing.assert_array_equal(obs.cpu().numpy(), orc.observe().numpy())   # identical state -> bit-identical float32 obs
     for t in range(60):
         a = pol.act(obs, deterministic=True).contiguous()
         obs, rew, done = env.step(a, diag=True)
