@@ -111,6 +111,12 @@ def default_params():
     return p
 
 
+def philox_block(seed, env_id, episode, block):
+    w = np.empty(4, np.uint32)
+    lib().orc_philox_block(C.c_uint64(seed), C.c_uint64(env_id), C.c_uint32(episode), C.c_uint32(block), _p(w))
+    return w
+
+
 def philox_uniforms(seed, env_id, episode):
     u = np.empty(24, np.float64)
     lib().orc_philox_uniforms(C.c_uint64(seed), C.c_uint64(env_id), C.c_uint32(episode), _p(u))

@@ -105,11 +105,24 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
   }
 }
 
+void orc_philox_block(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t block, uint32_t out[4]) {
+  uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), episode, block};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  memcpy(out, c, sizeof c);
+}
+
+/* 24 uniforms from 4 blocks: every 64-bit half of a block yields three 21-bit fields, u = (field + 0.5) / 2^21. */
 void orc_philox_uniforms(uint64_t seed, uint64_t env_id, uint32_t episode, double u[24]) {
-  for (uint32_t j = 0; j < 6; ++j) {
-    uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), episode, j};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    for (int i = 0; i < 4; ++i) u[4 * j + i] = ((double)c[i] + 0.5) * (1.0 / 4294967296.0);
+  for (uint32_t j = 0; j < 4; ++j) {
+    uint32_t c[4];
+    orc_philox_block(seed, env_id, episode, j, c);
+    for (int h = 0; h < 2; ++h) {
+      const uint32_t lo = c[2 * h], hi = c[2 * h + 1];
+      const uint32_t f0 = lo & 0x1FFFFFu, f1 = ((lo >> 21) | (hi << 11)) & 0x1FFFFFu, f2 = (hi >> 10) & 0x1FFFFFu;
+      u[6 * j + 3 * h + 0] = ((double)f0 + 0.5) * (1.0 / 2097152.0);
+      u[6 * j + 3 * h + 1] = ((double)f1 + 0.5) * (1.0 / 2097152.0);
+      u[6 * j + 3 * h + 2] = ((double)f2 + 0.5) * (1.0 / 2097152.0);
+    }
   }
 }
 

@@ -89,8 +89,9 @@ typedef struct OrcStepOut {
 int  orc_version(void);
 void orc_params_default(OrcParams* p);
 
-/* 24 uniforms in (0,1) for (seed, global env id, episode): Philox4x32-10, 6 blocks. */
+/* 24 uniforms in (0,1) for (seed, global env id, episode): Philox4x32-10, 4 blocks, 21 bits per uniform. */
 void orc_philox_uniforms(uint64_t seed, uint64_t env_id, uint32_t episode, double u[24]);
+void orc_philox_block(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t block, uint32_t out[4]);
 
 /* scalar pieces (exposed so tests can check them one by one against the importable reference functions) */
 void   orc_quat2mat(const double q[4], double m[9]);                               /* quaternions.py:48-68 */

@@ -26,7 +26,8 @@
 namespace rdv {
 
 // ---------------------------------------------------------------------------------------------------------------
-// Parameter block, derived once on the host (derive_params in rdv_hip.hip), read through a uniform pointer (s_load).
+// Parameter block, derived once on the host (derive_params in rdv_hip.hip).  The step kernels read it through a
+// top-level __restrict__ pointer to device memory, so every field is a scalar load into SGPRs (wave-uniform).
 struct DevParams {
   // Clohessy-Wiltshire state-transition matrix for (n, dt), the 14 non-zeros of dynamics.py:40-47
   double phi_xx, phi_xvx, phi_xvy;      // row 0: 4-3c, s/n, 2(1-c)/n
@@ -50,12 +51,14 @@ struct DevParams {
   double inv_corridor_norm, inv_capture_norm;
   double max_rd_error2, max_vd_error2, max_wd_error2;   // squared limits (:105-108)
   // thresholds on k = rint(1e5*cos) equivalent to the reference's tests on acos(round(cos,5)) (general.py:179)
+  double reset_flag_radius2;            // (max(koz_radius, |rd| + max_rd_error))^2: beyond it a fresh state has collided = success = 0
   double kc_coll_max;                   // in corridor cone test (:401): angle > half_angle      <=> k <= kc_coll_max
   double ka_done_max;                   // :370 attitude error > max_attitude_error               <=> k <= ka_done_max
   double ka_succ_min;                   // :417 attitude error <= max_qd_error                    <=> k >= ka_succ_min
   double ka_bonus_min;                  // :350 attitude error <  max_qd_error                    <=> k >= ka_bonus_min
   double bubble_radius0, bubble_decrease_rate, bubble_min;
   double att_term, coll_term, bonus_term;   // dt*att_coef, dt*collision_coef, dt*bonus_coef
+  const double* acos_table;                 // device: acos(k/1e5), k = -100000..100000, filled by the host's libm
   // reset (rendezvous_env.py:229-258); nominal quaternions pre-normalised (quat_product does it, quaternions.py:159-160)
   double nominal_rc0[3], nominal_vc0[3], nominal_qc0[4], nominal_wc0[3], nominal_qt0[4], nominal_wt0[3];
   double rc0_range, vc0_range, qc0_range, wc0_range, qt0_range, wt0_range;
@@ -172,30 +175,42 @@ __device__ __forceinline__ void integrate_attitude(double* q, const double* w, d
 }
 
 // Flags/reward inputs from the canonical state: one R(qc), one R(qt) per call (the reference rebuilds them ~10x per step).
+// kLazy (training kernels): the velocity / rotation-rate errors are only ever compared after the position error has
+// passed its limit (:417 np.all, :348), and the corridor angle only inside the KOZ sphere (:397); far from the target
+// they are skipped and set to +inf, which fails exactly the comparisons the reference would fail.
+template <bool kLazy>
 __device__ __forceinline__ void derive(const DevParams& P, const Env& e, Derived& d) {
   double Rc[9], Rt[9];
   quat2mat(e.qc, Rc);
   quat2mat(e.qt, Rt);
-  double cap_l[3], wc_l[3], wt_l[3], rd_l[3], corr_l[3];
+  double cap_l[3], rd_l[3];
   matvec(Rc, P.capture_axis, cap_l);    // :431
-  matvec(Rc, e.wc, wc_l);               // :458
-  matvec(Rt, e.wt, wt_l);               // :459
   matvec(Rt, P.rd, rd_l);               // :460
-  matvec(Rt, P.corridor_axis, corr_l);  // :400
-  const double vd_l[3] = {fma(wt_l[1], rd_l[2], -wt_l[2] * rd_l[1]), fma(wt_l[2], rd_l[0], -wt_l[0] * rd_l[2]),
-                          fma(wt_l[0], rd_l[1], -wt_l[1] * rd_l[0])};                   // :461
   const double dp[3] = {e.rc[0] - rd_l[0], e.rc[1] - rd_l[1], e.rc[2] - rd_l[2]};
-  const double dv[3] = {e.vc[0] - vd_l[0], e.vc[1] - vd_l[1], e.vc[2] - vd_l[2]};
-  const double dw[3] = {wc_l[0] - wt_l[0], wc_l[1] - wt_l[1], wc_l[2] - wt_l[2]};
   const double r2 = dot3(e.rc, e.rc);
   const double inv_dist = rsqrt64(r2);
   d.dist = r2 * inv_dist;
   d.pos2 = dot3(dp, dp);                // :463
-  d.vel2 = dot3(dv, dv);                // :464
-  d.rot2 = dot3(dw, dw);                // :466
   // general.py:179: round(cos, 5) == rint(cos*1e5)/1e5; rotations preserve |capture_axis|, |corridor_axis|
   d.k_att = rint(-dot3(e.rc, cap_l) * (inv_dist * P.inv_capture_norm) * 1e5);           // :432
-  d.k_corr = rint(dot3(e.rc, corr_l) * (inv_dist * P.inv_corridor_norm) * 1e5);         // :400
+  const double inf = __builtin_huge_val();
+  d.vel2 = inf; d.rot2 = inf; d.k_corr = inf;
+  if (!kLazy || d.pos2 <= P.max_rd_error2) {
+    double wc_l[3], wt_l[3];
+    matvec(Rc, e.wc, wc_l);             // :458
+    matvec(Rt, e.wt, wt_l);             // :459
+    const double vd_l[3] = {fma(wt_l[1], rd_l[2], -wt_l[2] * rd_l[1]), fma(wt_l[2], rd_l[0], -wt_l[0] * rd_l[2]),
+                            fma(wt_l[0], rd_l[1], -wt_l[1] * rd_l[0])};                 // :461
+    const double dv[3] = {e.vc[0] - vd_l[0], e.vc[1] - vd_l[1], e.vc[2] - vd_l[2]};
+    const double dw[3] = {wc_l[0] - wt_l[0], wc_l[1] - wt_l[1], wc_l[2] - wt_l[2]};
+    d.vel2 = dot3(dv, dv);              // :464
+    d.rot2 = dot3(dw, dw);              // :466
+  }
+  if (!kLazy || d.dist < P.koz_radius) {
+    double corr_l[3];
+    matvec(Rt, P.corridor_axis, corr_l);                                                // :400
+    d.k_corr = rint(dot3(e.rc, corr_l) * (inv_dist * P.inv_corridor_norm) * 1e5);
+  }
 }
 
 // k / 1e5 correctly rounded (k is an integer-valued double, |k| <= 1e5): product by 1e-5 plus one residual correction
@@ -204,6 +219,15 @@ __device__ __forceinline__ double div_1e5(double k) {
   return fma(fma(-q, 1e5, k), 1e-5, q);
 }
 __device__ __forceinline__ double angle_of(double k) { return acos(div_1e5(k)); }     // general.py:179
+// The same value on the step path: a rounded cosine takes one of 200,001 values k*1e-5, so acos(k/1e5) is read from a
+// 1.6 MB table the host fills with its libm acos (the oracle's), instead of ~110 instructions of device acos.  Only the
+// ~14k entries of attitude errors below 30 deg are ever touched (episodes end beyond): ~110 KB, L2-resident.
+__device__ __forceinline__ double attitude_error_of(const DevParams& P, double k) {
+  const bool valid = fabs(k) <= 100000.0;                    // false for NaN (rc = 0: the reference asserts there)
+  const int idx = valid ? (int)k + 100000 : 100000;
+  const double a = P.acos_table[idx];
+  return valid ? a : __builtin_nan("");
+}
 
 // check_collision (:388-404)
 __device__ __forceinline__ bool in_koz(const DevParams& P, const Derived& d) {
@@ -270,13 +294,16 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // one full 32x32->64 product each (v_mad_u64_u32) instead of separate quarter-rate mul_hi + mul_lo
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
     const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
     c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
   }
 }
-__device__ __forceinline__ double u01(uint32_t x) { return ((double)x + 0.5) * (1.0 / 4294967296.0); }
+// 21-bit uniform in (0,1).  A reset needs 24 uniforms = 504 bits = 4 Philox blocks (three 21-bit fields per 64 bits);
+// 32-bit integer multiplies are quarter-rate on CDNA, so the block count is what a reset costs.
+__device__ __forceinline__ double u21(uint32_t field) { return ((double)field + 0.5) * (1.0 / 2097152.0); }
 
 // general.py:248-254: uniform(-1,1,3) normalised (cube-normalised direction, as the reference)
 __device__ __forceinline__ void unit_vector(double u0, double u1, double u2, double* o) {
@@ -320,10 +347,11 @@ __device__ __forceinline__ void reset_state(const DevParams& P, Env& e, uint64_t
   } else {
     double u[24];
 #pragma unroll
-    for (uint32_t j = 0; j < 6; ++j) {
+    for (uint32_t j = 0; j < 4; ++j) {
       uint32_t c0 = (uint32_t)env_id, c1 = (uint32_t)(env_id >> 32), c2 = e.episode, c3 = j;
       philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
-      u[4 * j + 0] = u01(c0); u[4 * j + 1] = u01(c1); u[4 * j + 2] = u01(c2); u[4 * j + 3] = u01(c3);
+      u[6 * j + 0] = u21(c0 & 0x1FFFFFu); u[6 * j + 1] = u21(((c0 >> 21) | (c1 << 11)) & 0x1FFFFFu); u[6 * j + 2] = u21((c1 >> 10) & 0x1FFFFFu);
+      u[6 * j + 3] = u21(c2 & 0x1FFFFFu); u[6 * j + 4] = u21(((c2 >> 21) | (c3 << 11)) & 0x1FFFFFu); u[6 * j + 5] = u21((c3 >> 10) & 0x1FFFFFu);
     }
     double dir[3], tmp[3], R[9];
     unit_vector(u[0], u[1], u[2], dir);                                   // :231
@@ -356,11 +384,17 @@ __device__ __forceinline__ void reset_state(const DevParams& P, Env& e, uint64_t
   for (int i = 0; i < 3; ++i) { e.rc[i] = canon(e.rc[i], tag); e.vc[i] = canon(e.vc[i], tag); e.wc[i] = canon(e.wc[i], tag); e.wt[i] = canon(e.wt[i], tag); }
 #pragma unroll
   for (int i = 0; i < 4; ++i) { e.qc[i] = canon(e.qc[i], tag); e.qt[i] = canon(e.qt[i], tag); }
-  Derived d;
-  derive(P, e, d);
-  const bool coll = in_koz(P, d);                                         // :261
-  const bool succ = !coll && errors_ok(P, d);                             // :262
-  e.flags = (coll ? FLAG_COLLIDED : 0u) | ((succ ? 1u : 0u) << SUCCESS_SHIFT);
+  // :261-262 collided = check_collision(), success = int(check_success()).  Both need the chaser within
+  // max(koz_radius, |rd| + max_rd_error) of the target (inside the KOZ sphere, resp. position error <= max_rd_error);
+  // the nominal start is 10 m out, so the rotation matrices and errors are only built for states that close.
+  e.flags = 0u;
+  if (dot3(e.rc, e.rc) < P.reset_flag_radius2) {
+    Derived d;
+    derive<true>(P, e, d);
+    const bool coll = in_koz(P, d);
+    const bool succ = !coll && errors_ok(P, d);
+    e.flags = (coll ? FLAG_COLLIDED : 0u) | ((succ ? 1u : 0u) << SUCCESS_SHIFT);
+  }
 }
 
 // the bookkeeping half of reset (:263-266)
@@ -387,7 +421,7 @@ struct StepResult {
 };
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
-template <typename ST>
+template <typename ST, bool kLazy>
 __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d) {
   const ST tag = ST(0);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
@@ -416,7 +450,7 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
 #pragma unroll
   for (int i = 0; i < 4; ++i) { e.qc[i] = canon(e.qc[i], tag); e.qt[i] = canon(e.qt[i], tag); }
 
-  derive(P, e, d);
+  derive<kLazy>(P, e, d);
   const bool inst_coll = in_koz(P, d);
   // :187-190
   if (!(e.flags & FLAG_COLLIDED)) {
@@ -440,7 +474,7 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
   r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
   // :313-353
-  const double att = angle_of(d.k_att);
+  const double att = attitude_error_of(P, d.k_att);
   double rew = P.att_term * fma(-att, P.inv_max_attitude_error, 1.0);                  // :329
   rew += (double)(mul_f32_rn(P.fuel_scale_f32, sum_v) / P.fuel_div_f32);               // :333
   if (inst_coll) rew -= P.coll_term;                                                   // :336-337

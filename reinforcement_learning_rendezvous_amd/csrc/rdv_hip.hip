@@ -72,20 +72,28 @@ __device__ __forceinline__ void store_env(typename Vec4<ST>::type* __restrict__ 
   if (with_wt) { c.x = (ST)e.wt[0]; c.y = (ST)e.wt[1]; c.z = (ST)e.wt[2]; c.w = ST(0); ws[6 * n + i] = c; }
 }
 
-// wave64 butterfly sums (ds_bpermute/DPP); every lane ends with the total, in a fixed order -> deterministic
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-  return v;
-}
-__device__ __forceinline__ int wave_sum(int v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, kWave);
-  return v;
-}
+// Diagnostic build only (-DRDV_STAMPS, tools/stamp_profile.py): s_memtime stamps at the phase boundaries of the split
+// kernel, written to a buffer nothing else reads.  In the product build these macros expand to nothing.
+#ifdef RDV_STAMPS
+#define RDV_STAMP_DECL unsigned long long stamp_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; stamp_[8] = __builtin_amdgcn_s_memrealtime();
+#define RDV_STAMP(k)                                   \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    stamp_[k] = __builtin_readcyclecounter();          \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+#define RDV_STAMP_FLUSH(wave_id)                                                              \
+  if (A.stamps && lane == 0) {                                                                \
+    stamp_[9] = __builtin_amdgcn_s_memrealtime();                                           \
+    for (int s_ = 0; s_ < 10; ++s_) A.stamps[(uint64_t)(wave_id) * 10 + s_] = stamp_[s_];     \
+  }
+#else
+#define RDV_STAMP_DECL
+#define RDV_STAMP(k)
+#define RDV_STAMP_FLUSH(wave_id)
+#endif
 
 struct StepArgs {
-  const DevParams* __restrict__ P;   // device copy of the parameter block (uniform -> scalar loads)
   void* ws;                 // chunk arrays
   uint64_t* stats;          // [n_waves][16]
   const float* actions;     // [N,6]
@@ -103,6 +111,9 @@ struct StepArgs {
   uint64_t env_id_offset;
   int32_t tape_depth;
   int32_t on_done;
+#ifdef RDV_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
 // LDS exchanged inside ONE wave (wave-private region): LDS operations of a wave execute in issue order, so only the
@@ -155,10 +166,21 @@ __device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t 
   }
 }
 
-// Episode statistics of one wave of envs: wavefront reductions (ballot/popcount for the counters, butterfly sums for
-// the reals), then lanes 0..11 update the wave's private 128-byte slot with plain read-modify-writes.
-__device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, int lane, bool stepped, bool fin, int reason,
-                                             uint32_t flags, int k, double ep_ret, double sum_dv, double sum_dw) {
+// Episode statistics of one wave of envs, as wavefront reductions: ballot + popcount for the counters; the sums run over
+// the finished lanes only (they are sparse: ~1-5 % of envs end per step), picked out of the ballot mask in ascending lane
+// order with v_readlane — a fixed order, so the fp64 sums are reproducible.  Lanes 0..11 then write the wave's private
+// 128-byte slot; `pre` is that slot's previous content, loaded by lanes 0..11 at kernel entry so that no memory
+// latency is paid here.
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ uint64_t stats_preload(const uint64_t* __restrict__ slot, int lane) {
+  return lane < 12 ? slot[lane] : 0ull;
+}
+__device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, uint64_t pre, int lane, bool stepped, bool fin,
+                                             int reason, uint32_t flags, int k, double ep_ret, double sum_dv, double sum_dw) {
   const unsigned long long m_step = __ballot(stepped);
   const unsigned long long m_fin = __ballot(fin);
   if (m_step == 0ull) return;   // wave-uniform
@@ -167,35 +189,40 @@ __device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, int la
     const unsigned long long m_coll = __ballot(fin && (flags & FLAG_COLLIDED));
     const unsigned long long m_r1 = __ballot(fin && reason == 1), m_r2 = __ballot(fin && reason == 2);
     const unsigned long long m_r3 = __ballot(fin && reason == 3), m_r4 = __ballot(fin && reason == 4);
-    const int s_len = wave_sum(fin ? k : 0);
-    const double s_ret = wave_sum(fin ? ep_ret : 0.0);
-    const double s_dv = wave_sum(fin ? sum_dv : 0.0);
-    const double s_dw = wave_sum(fin ? sum_dw : 0.0);
+    int s_len = 0;
+    double s_ret = 0.0, s_dv = 0.0, s_dw = 0.0;
+    for (unsigned long long m = m_fin; m != 0ull; m &= m - 1ull) {   // scalar loop over the finished lanes
+      const int src = __builtin_ctzll(m);
+      s_len += __builtin_amdgcn_readlane(k, src);
+      s_ret += readlane_f64(ep_ret, src);
+      s_dv += readlane_f64(sum_dv, src);
+      s_dw += readlane_f64(sum_dw, src);
+    }
     if (lane < 12) {
-      uint64_t iv = 0; double dv = 0.0;
-      switch (lane) {
-        case ST_STEPS: iv = __popcll(m_step); break;
-        case ST_EPISODES: iv = __popcll(m_fin); break;
-        case ST_SUCCESS: iv = __popcll(m_succ); break;
-        case ST_COLLIDED: iv = __popcll(m_coll); break;
-        case ST_REASON0: iv = __popcll(m_r1); break;
-        case ST_REASON1: iv = __popcll(m_r2); break;
-        case ST_REASON2: iv = __popcll(m_r3); break;
-        case ST_REASON3: iv = __popcll(m_r4); break;
-        case ST_SUM_LEN: iv = (uint64_t)s_len; break;
-        case ST_SUM_RET: dv = s_ret; break;
-        case ST_SUM_DV: dv = s_dv; break;
-        default: dv = s_dw; break;
-      }
-      if (lane <= ST_SUM_LEN) slot[lane] += iv;
-      else reinterpret_cast<double*>(slot)[lane] += dv;
+      // straight-line selects (a switch on the lane id compiles to a tree of exec-masked branches)
+      uint32_t iv = (uint32_t)__popcll(m_step);
+      iv = lane == ST_EPISODES ? (uint32_t)__popcll(m_fin) : iv;
+      iv = lane == ST_SUCCESS ? (uint32_t)__popcll(m_succ) : iv;
+      iv = lane == ST_COLLIDED ? (uint32_t)__popcll(m_coll) : iv;
+      iv = lane == ST_REASON0 ? (uint32_t)__popcll(m_r1) : iv;
+      iv = lane == ST_REASON1 ? (uint32_t)__popcll(m_r2) : iv;
+      iv = lane == ST_REASON2 ? (uint32_t)__popcll(m_r3) : iv;
+      iv = lane == ST_REASON3 ? (uint32_t)__popcll(m_r4) : iv;
+      iv = lane == ST_SUM_LEN ? (uint32_t)s_len : iv;
+      double dv = s_ret;
+      dv = lane == ST_SUM_DV ? s_dv : dv;
+      dv = lane == ST_SUM_DW ? s_dw : dv;
+      const uint64_t as_int = pre + iv;
+      const uint64_t as_real = (uint64_t)__double_as_longlong(__longlong_as_double((long long)pre) + dv);
+      slot[lane] = lane <= ST_SUM_LEN ? as_int : as_real;
     }
   } else if (lane == 0) {
-    slot[ST_STEPS] += __popcll(m_step);
+    slot[ST_STEPS] = pre + __popcll(m_step);
   }
 }
 
 // per-env outputs of a transition (coalesced 4-/1-byte stores; the sparse ones only where an episode ended)
+template <bool kTerminalObs>
 __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i, bool active, bool fin, const StepResult& r,
                                                    const Env& e) {
   if (active) {
@@ -206,7 +233,7 @@ __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i,
                                    ((fin && (e.flags >> SUCCESS_SHIFT) != 0u) ? 32 : 0));
   }
   if (fin) {
-    if (A.terminal_obs) {
+    if (kTerminalObs && A.terminal_obs) {
       float* t = A.terminal_obs + i * RDV_OBS_DIM;
 #pragma unroll
       for (int j = 0; j < RDV_OBS_DIM; ++j) t[j] = r.obs[j];
@@ -229,9 +256,9 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
     if (e.flags & FLAG_HALTED) {
       observation(P, e, r.obs);
       r.done = 1;
-      if (kDiag) { derive(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
+      if (kDiag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
     } else {
-      step_env<ST>(P, e, a, r, d);
+      step_env<ST, !kDiag>(P, e, a, r, d);
       stepped = true;
       if (kDiag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);   // evaluator build only: keeps the training kernel short
     }
@@ -243,10 +270,20 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
 // Fused variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).
 // The right shape when the chip is full (several waves per SIMD): no work is done twice.
 template <typename ST, bool kDiag>
-__global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
+__global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+                                                       uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
+  // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
+  // at wave launch (-mllvm -amdgpu-kernarg-preload-count=16) instead of being fetched from the host-visible kernarg
+  // segment; the rest of the argument block is read later, off the critical path.
+  StepArgs A = A_rest;
+  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
   using V = typename Vec4<ST>::type;
   __shared__ __attribute__((aligned(16))) float lds[kBlock * RDV_OBS_DIM];   // 17,408 B: wave-private staging regions
-  const DevParams& P = *A.P;
+  // The parameter block sits in device memory behind a top-level __restrict__ pointer: nothing the kernel stores can alias
+  // it, so its fields are fetched with scalar loads from HBM/L2.  (By value it would travel in the kernarg segment, which
+  // every wave reads from host-visible memory: +1 us per launch measured; behind a pointer inside a struct the compiler
+  // cannot prove the no-alias and emits uniform-address VECTOR loads in the middle of the math.)
+  const DevParams& P = *Pp;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave_in_block = threadIdx.x >> 6;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -259,15 +296,16 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
 
   Env e;
   if (active) load_env<ST>(ws, n, i, e);   // 7 x 16-byte-per-lane loads, issued before anything depends on them
+  uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
+  const uint64_t slot_pre = stats_preload(slot, lane);
   float a[RDV_ACT_DIM];
   load_actions(A.actions, wave_base, rows, lane, active, wl, a);
 
   StepResult r;
   const bool stepped = advance<ST, kDiag>(A, P, i, active, e, a, r);
   const bool fin = stepped && r.done;
-  stats_update(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret,
-               e.sum_dv, e.sum_dw);
-  store_step_outputs(A, i, active, fin, r, e);
+  stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+  store_step_outputs<true>(A, i, active, fin, r, e);
   bool did_reset = false;
   if (fin) {
     if (A.on_done == RDV_ON_DONE_RESET) {
@@ -291,134 +329,120 @@ __global__ __launch_bounds__(kBlock) void step_kernel(const StepArgs A) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Split-role variant for a chip that is NOT full (N <= ~128k envs leaves one wave per SIMD, and a lone wave issues at
-// half the SIMD's rate): a 256-thread workgroup owns 128 envs.  Waves 0-1 ("step waves") advance them; waves 2-3
-// ("service waves") run beside them on the same CU and take everything that does not depend on the step off the
-// critical path: they compute every env's NEXT initial state (it depends only on seed, env id and episode index) into
-// LDS while the step runs, then reduce the episode statistics and issue the coalesced observation stores.  A finished
-// env picks its new state up from LDS instead of running the reset in-lane.  Same arithmetic, same results as the
-// fused variant (tests run both); roughly twice the instructions issued, about half the critical path.
-constexpr int kSplitEnvs = 128;
-template <typename ST> struct ResetRec { static constexpr int kWords = 20 * (int)(sizeof(ST) / 4) + 1; };   // odd stride: conflict-free
-constexpr int kFinWords = 7;   // meta word + ep_return, sum_dv, sum_dw as fp64
+// Split-role variant for a chip that is NOT full (N <= ~128k envs is at most two waves per SIMD): a 512-thread workgroup
+// owns 256 envs.  Waves 0-3 ("step waves") do the whole transition for their 64 envs exactly as the fused kernel does,
+// except the in-lane reset.  Waves 4-7 ("service waves") run beside them — an 8-wave workgroup places waves w and w+4 on
+// the same SIMD, so every SIMD holds one of each — and compute every env's NEXT initial state and observation while the
+// step runs (they depend only on seed, env id and episode index).  After the single workgroup barrier a service lane
+// whose env finished writes that state and observation straight to HBM; the step waves have nothing left to do.
+// Same arithmetic, same results as the fused variant (tests run both).  The next-state work is done for every env and
+// used by ~5 %: it costs issue slots that are idle at this size, and takes the reset (as long as the step itself)
+// off the critical path.
+constexpr int kSplitEnvs = 256;      // envs per workgroup
+constexpr int kSplitBlock = 512;     // 8 waves
 
 template <typename ST, bool kDiag>
-__global__ __launch_bounds__(kBlock) void step_kernel_split(const StepArgs A) {
+__global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+                                                       uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
+  // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
+  // at wave launch (-mllvm -amdgpu-kernarg-preload-count=16) instead of being fetched from the host-visible kernarg
+  // segment; the rest of the argument block is read later, off the critical path.
+  StepArgs A = A_rest;
+  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
   using V = typename Vec4<ST>::type;
-  constexpr int kRec = ResetRec<ST>::kWords;
-  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // actions, then observations
-  __shared__ uint32_t recs[kSplitEnvs * kRec];                                       // next initial state per env
-  __shared__ uint32_t fins[kSplitEnvs * kFinWords];                                  // statistics inputs per env
-  const DevParams& P = *A.P;
+  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // actions, then observation rows
+  __shared__ unsigned long long fin_mask[kSplitEnvs / kWave];                        // per step wave: lanes to reset
+  const DevParams& P = *Pp;   // scalar loads: see step_kernel
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
-  const bool step_role = wv < 2;
+  const bool step_role = wv < kSplitEnvs / kWave;
   const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);          // both roles: the env this lane is responsible for
   const int64_t i = (int64_t)blockIdx.x * kSplitEnvs + slot_in_block;
   const int64_t wave_base = i - lane;
   const int64_t n = A.n;
   const bool active = i < n;
   const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
-  float* wl = stage + (wv & 1) * (kWave * RDV_OBS_DIM);
-  uint32_t* rec = recs + slot_in_block * kRec;
-  uint32_t* fr = fins + slot_in_block * kFinWords;
   V* ws = reinterpret_cast<V*>(A.ws);
   const bool resets = A.on_done == RDV_ON_DONE_RESET;
+  RDV_STAMP_DECL
+  RDV_STAMP(0);
 
-  Env e;
-  StepResult r;
-  bool stepped = false, fin = false, did_reset = false;
   if (step_role) {
+    // ------------------------------------------------------------------ step waves
+    float* wl = stage + wv * (kWave * RDV_OBS_DIM);
+    Env e;
+    StepResult r;
     if (active) load_env<ST>(ws, n, i, e);
+    uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
+    const uint64_t slot_pre = stats_preload(slot, lane);
     float a[RDV_ACT_DIM];
     load_actions(A.actions, wave_base, rows, lane, active, wl, a);
-    stepped = advance<ST, kDiag>(A, P, i, active, e, a, r);
-    fin = stepped && r.done;
-    // statistics inputs for the service wave
-    fr[0] = (stepped ? 1u : 0u) | (fin ? 2u : 0u) | ((uint32_t)r.reason << 2) | (((e.flags >> SUCCESS_SHIFT) != 0u) ? 32u : 0u) |
-            ((e.flags & FLAG_COLLIDED) ? 64u : 0u) | ((uint32_t)e.k << 8);
-    if (fin) {
-      const unsigned long long b0 = (unsigned long long)__double_as_longlong(e.ep_ret), b1 = (unsigned long long)__double_as_longlong(e.sum_dv),
-                               b2 = (unsigned long long)__double_as_longlong(e.sum_dw);
-      fr[1] = (uint32_t)b0; fr[2] = (uint32_t)(b0 >> 32); fr[3] = (uint32_t)b1; fr[4] = (uint32_t)(b1 >> 32);
-      fr[5] = (uint32_t)b2; fr[6] = (uint32_t)(b2 >> 32);
-    }
-    store_step_outputs(A, i, active, fin, r, e);
-  } else if (resets && active) {
-    // service wave: the env's next initial state, computed while the step waves work
-    const V c5 = ws[5 * n + i];
-    Env ne;
-    ne.episode = s2u(c5.w);
-    const double* row = nullptr;
-    if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
-    reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
-    const double* st = ne.rc;   // rc vc qc wc qt wt are 20 contiguous doubles
-    if (sizeof(ST) == 4) {
-#pragma unroll
-      for (int j = 0; j < 20; ++j) rec[j] = __float_as_uint((float)st[j]);
-    } else {
-#pragma unroll
-      for (int j = 0; j < 20; ++j) {
-        const unsigned long long b = (unsigned long long)__double_as_longlong(st[j]);
-        rec[2 * j] = (uint32_t)b; rec[2 * j + 1] = (uint32_t)(b >> 32);
-      }
-    }
-    rec[kRec - 1] = ne.flags;
-  }
-  __syncthreads();   // B1: next initial states and statistics inputs are in LDS
-
-  if (step_role) {
-    if (fin) {
-      if (resets) {   // auto-reset (SB3 DummyVecEnv semantics): adopt the precomputed state
-        double* st = e.rc;
-        if (sizeof(ST) == 4) {
-#pragma unroll
-          for (int j = 0; j < 20; ++j) st[j] = (double)__uint_as_float(rec[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 20; ++j) st[j] = __longlong_as_double((long long)(((unsigned long long)rec[2 * j + 1] << 32) | rec[2 * j]));
-        }
-        e.flags = rec[kRec - 1];
-        reset_aux<ST>(P, e);
-        observation(P, e, r.obs);
-        did_reset = true;
-      } else {
-        e.flags |= FLAG_HALTED;
-      }
-    }
+    RDV_STAMP(1);
+    const bool stepped = advance<ST, kDiag>(A, P, i, active, e, a, r);
+    RDV_STAMP(2);
+    const bool fin = stepped && r.done;
+    const bool to_reset = fin && resets;
+    const unsigned long long m_reset = __ballot(to_reset);
+    if (lane == 0) fin_mask[wv] = m_reset;
+    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+    store_step_outputs<true>(A, i, active, fin, r, e);
+    RDV_STAMP(3);
+    if (fin && !resets) e.flags |= FLAG_HALTED;
+    // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores.  If an env of this wave resets,
+    // the rows stay in LDS: the service wave swaps in the reset observation and stores the block after the barrier.
 #pragma unroll
     for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
+    wave_lds_fence();
+    if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
+    RDV_STAMP(4);
+    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
+    RDV_STAMP(5);
+    RDV_STAMP(6);
+    __syncthreads();
   } else {
-    const uint32_t meta = fr[0];
-    const bool s_stepped = active && (meta & 1u), s_fin = active && (meta & 2u);
-    double v0 = 0.0, v1 = 0.0, v2 = 0.0;
-    if (s_fin) {
-      v0 = __longlong_as_double((long long)(((unsigned long long)fr[2] << 32) | fr[1]));
-      v1 = __longlong_as_double((long long)(((unsigned long long)fr[4] << 32) | fr[3]));
-      v2 = __longlong_as_double((long long)(((unsigned long long)fr[6] << 32) | fr[5]));
+    // ------------------------------------------------------------------ service waves
+    Env ne;
+    float robs[RDV_OBS_DIM];
+    if (resets && active) {
+      const V c5 = ws[5 * n + i];
+      ne.episode = s2u(c5.w);
+      RDV_STAMP(1);
+      const double* row = nullptr;
+      if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
+      reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+      reset_aux<ST>(P, ne);
+      observation(P, ne, robs);
+      RDV_STAMP(2);
     }
-    const uint32_t fl = ((meta & 32u) ? (1u << SUCCESS_SHIFT) : 0u) | ((meta & 64u) ? FLAG_COLLIDED : 0u);
-    stats_update(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, lane, s_stepped, s_fin, (int)((meta >> 2) & 7u), fl,
-                 (int)(meta >> 8), v0, v1, v2);
+    RDV_STAMP(3);
+    __syncthreads();
+    RDV_STAMP(4);
+    const unsigned long long m_reset = fin_mask[wv - kSplitEnvs / kWave];
+    if (m_reset != 0ull) {   // wave-uniform: some env of the step wave we serve finished its episode
+      float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
+      if (active && ((m_reset >> lane) & 1ull)) {
+        // auto-reset (SB3 DummyVecEnv semantics): the new state to HBM, the first observation of the next episode into the row
+        store_env<ST>(ws, n, i, ne, true);
+#pragma unroll
+        for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
+      }
+      wave_lds_fence();
+      store_obs_rows(A.obs, wave_base, rows, lane, wl);
+    }
+    RDV_STAMP(6);
   }
-  __syncthreads();   // B2: the observation rows (reset ones included) are staged
-
-  if (step_role) {
-    if (stepped) store_env<ST>(ws, n, i, e, did_reset);
-  } else {
-    store_obs_rows(A.obs, wave_base, rows, lane, wl);
-  }
+  RDV_STAMP(7);
+  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + wv)
 }
 
 // reset() for all envs or where mask != 0
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams* __restrict__ Pp, void* ws_, int64_t n, const uint8_t* mask,
+__global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams P, void* ws_, int64_t n, const uint8_t* mask,
                                                        float* obs, const double* tape, int32_t tape_depth, uint64_t seed,
                                                        uint64_t env_id_offset, int fresh) {
   using V = typename Vec4<ST>::type;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const DevParams& P = *Pp;
   V* ws = reinterpret_cast<V*>(ws_);
   if (mask && !mask[i]) return;
   Env e;
@@ -439,12 +463,11 @@ enum { ACC_SET_STATE = 0, ACC_GET_STATE, ACC_GET_AUX, ACC_OBSERVE, ACC_DIAGNOSE 
 
 // state access / evaluator helpers (cold paths; one lane per env, row-major host-facing arrays)
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void access_kernel(const DevParams* __restrict__ Pp, void* ws_, int64_t n, int what, const double* in,
+__global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void* ws_, int64_t n, int what, const double* in,
                                                         double* out, float* out_f32) {
   using V = typename Vec4<ST>::type;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  const DevParams& P = *Pp;
   V* ws = reinterpret_cast<V*>(ws_);
   Env e;
   load_env<ST>(ws, n, i, e);
@@ -468,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void access_kernel(const DevParams* __restr
     for (int j = 0; j < RDV_OBS_DIM; ++j) out_f32[i * RDV_OBS_DIM + j] = o[j];
   } else {
     Derived d;
-    derive(P, e, d);
+    derive<false>(P, e, d);
     diagnostics(P, e, d, out + i * RDV_DIAG_DIM);
   }
 }
@@ -495,6 +518,8 @@ static inline int64_t n_waves(int64_t n) { return (n + kBlock - 1) / kBlock * (k
 static inline int64_t chunk_bytes(int64_t n, int storage) { return align_up(kChunks * n * 4 * (storage == RDV_STORAGE_F64 ? 8 : 4), 256); }
 static inline int64_t stats_bytes(int64_t n) { return align_up(n_waves(n) * kStatWords * (int64_t)sizeof(uint64_t), 256); }
 static inline int64_t params_bytes() { return align_up((int64_t)sizeof(DevParams), 256); }
+constexpr int kAcosEntries = 200001;   // acos(k/1e5), k = -100000..100000 (general.py:179 rounds every cosine to 5 decimals)
+static inline int64_t acos_bytes() { return align_up((int64_t)kAcosEntries * (int64_t)sizeof(double), 256); }
 
 // Largest integer k in [-100000, 100000] for which acos(k/1e5) > theta (strict) or >= theta; -100001 if there is none.
 // acos(k/1e5) is what general.py:179 evaluates for every cosine that rounds to k*1e-5, so comparing k with this
@@ -541,6 +566,10 @@ static void derive_params(const RdvParams& p, DevParams& d) {
   for (int i = 0; i < 3; ++i) { d.corridor_axis[i] = p.corridor_axis[i]; d.capture_axis[i] = p.capture_axis[i]; d.rd[i] = p.rd[i]; }
   d.inv_corridor_norm = 1.0 / norm3h(p.corridor_axis); d.inv_capture_norm = 1.0 / norm3h(p.capture_axis);
   d.max_rd_error2 = p.max_rd_error * p.max_rd_error; d.max_vd_error2 = p.max_vd_error * p.max_vd_error; d.max_wd_error2 = p.max_wd_error * p.max_wd_error;
+  {  // an initial state can only be inside the KOZ sphere or meet the capture position error within this radius of the target
+    const double rr = std::fmax(p.koz_radius, norm3h(p.rd) + p.max_rd_error) * (1.0 + 1e-9);
+    d.reset_flag_radius2 = rr * rr;
+  }
   d.kc_coll_max = largest_k_with_angle_above(p.corridor_half_angle, true);        // :401  angle >  half_angle
   d.ka_done_max = largest_k_with_angle_above(p.max_attitude_error, true);         // :370  att   >  max_attitude_error
   d.ka_succ_min = largest_k_with_angle_above(p.max_qd_error, true) + 1.0;         // :417  att   <= max_qd_error
@@ -578,12 +607,16 @@ struct RdvEnvBatch {
   uint64_t seed, env_id_offset;
   void* ws;          // chunks
   uint64_t* stats;   // slots
-  DevParams* dev_params;   // device copy of `dev`
+  DevParams* dev_params;   // device copy of `dev`, read by the step kernels
+  double* acos_table;      // device, kAcosEntries doubles
   bool own_ws;
   bool fresh;        // no reset yet since create/seed
   const double* tape;
   int32_t tape_depth;
   int variant;       // RdvKernelVariant
+#ifdef RDV_STAMPS
+  unsigned long long* stamps = nullptr;
+#endif
   std::vector<uint64_t> host_slots;
 };
 static constexpr uint32_t kMagic = 0x52445631u;   // "RDV1"
@@ -635,7 +668,7 @@ int rdv_params_validate(const RdvParams* p) {
 
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
   if (n_envs <= 0 || (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64)) return -1;
-  return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes();
+  return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes() + acos_bytes();
 }
 
 int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
@@ -667,9 +700,16 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   }
   h->stats = reinterpret_cast<uint64_t*>(static_cast<char*>(h->ws) + chunk_bytes(n_envs, storage));
   h->dev_params = reinterpret_cast<DevParams*>(reinterpret_cast<char*>(h->stats) + stats_bytes(n_envs));
+  h->acos_table = reinterpret_cast<double*>(reinterpret_cast<char*>(h->dev_params) + params_bytes());
+  h->dev.acos_table = h->acos_table;
   hipError_t err = hipMemset(h->ws, 0, (size_t)bytes);
+  if (err == hipSuccess) {
+    std::vector<double> table((size_t)kAcosEntries);
+    for (int k = 0; k < kAcosEntries; ++k) table[(size_t)k] = std::acos((double)(k - 100000) / 1e5);   // the oracle's expression
+    err = hipMemcpy(h->acos_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice);
+  }
   if (err == hipSuccess) err = hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice);
-  if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset/hipMemcpy of the workspace failed: %s", hipGetErrorString(err)); }
+  if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset of the workspace failed: %s", hipGetErrorString(err)); }
   h->host_slots.resize((size_t)(n_waves(n_envs) * kStatWords));
   *out = h;
   return RDV_OK;
@@ -690,6 +730,7 @@ int rdv_set_params(rdv_handle h, const RdvParams* p) {
   if (int rc = rdv_params_validate(p)) return rc;
   DeviceGuard guard(h->device);
   h->params = *p; derive_params(*p, h->dev);
+  h->dev.acos_table = h->acos_table;
   // blocking copy on the legacy default stream: ordered after work already enqueued on blocking streams
   RDV_HIP(hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice));
   return RDV_OK;
@@ -705,6 +746,13 @@ int rdv_seed(rdv_handle h, uint64_t seed) {
   h->seed = seed; h->fresh = true;
   return RDV_OK;
 }
+#ifdef RDV_STAMPS
+int rdv_debug_set_stamps(rdv_handle h, unsigned long long* stamps) {   // diagnostic build only; [n_waves_launched][8]
+  RDV_CHECK_HANDLE(h);
+  h->stamps = stamps;
+  return RDV_OK;
+}
+#endif
 int rdv_set_kernel_variant(rdv_handle h, int variant) {
   RDV_CHECK_HANDLE(h);
   if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT)
@@ -728,9 +776,9 @@ int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream) {
   const int fresh = (h->fresh && !mask) ? 1 : 0;
   if (h->fresh && mask) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_reset: the first reset after create/seed must cover all envs (mask = NULL)");
   if (h->storage == RDV_STORAGE_F32)
-    hipLaunchKernelGGL(reset_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
+    hipLaunchKernelGGL(reset_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
   else
-    hipLaunchKernelGGL(reset_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
+    hipLaunchKernelGGL(reset_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
   RDV_HIP(hipGetLastError());
   h->fresh = false;
   return RDV_OK;
@@ -746,23 +794,26 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   if (out->diag && (reinterpret_cast<uintptr_t>(out->diag) & 7)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: diag must be 8-byte aligned");
   DeviceGuard guard(h->device);
   StepArgs A;
-  A.P = h->dev_params; A.ws = h->ws; A.stats = h->stats; A.actions = actions;
+  A.ws = h->ws; A.stats = h->stats; A.actions = actions;
   A.obs = out->obs; A.reward = out->reward; A.done = out->done; A.terminal_obs = out->terminal_obs;
   A.episode_return = out->episode_return; A.episode_length = out->episode_length; A.done_reason = out->done_reason;
   A.diag = out->diag; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done;
+#ifdef RDV_STAMPS
+  A.stamps = h->stamps;
+#endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool split = h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs);
-  const dim3 block(kBlock);
+  const dim3 block(split ? kSplitBlock : kBlock);
   const dim3 grid = split ? dim3((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)) : grid_for(h->n);
 #define RDV_LAUNCH_STEP(KERNEL)                                                         \
   do {                                                                                  \
     if (h->storage == RDV_STORAGE_F32) {                                                \
-      if (A.diag) hipLaunchKernelGGL((KERNEL<float, true>), grid, block, 0, s, A);      \
-      else hipLaunchKernelGGL((KERNEL<float, false>), grid, block, 0, s, A);            \
+      if (A.diag) hipLaunchKernelGGL((KERNEL<float, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);      \
+      else hipLaunchKernelGGL((KERNEL<float, false>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);            \
     } else {                                                                            \
-      if (A.diag) hipLaunchKernelGGL((KERNEL<double, true>), grid, block, 0, s, A);     \
-      else hipLaunchKernelGGL((KERNEL<double, false>), grid, block, 0, s, A);           \
+      if (A.diag) hipLaunchKernelGGL((KERNEL<double, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);     \
+      else hipLaunchKernelGGL((KERNEL<double, false>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);           \
     }                                                                                   \
   } while (0)
   if (split) RDV_LAUNCH_STEP(step_kernel_split);
@@ -775,8 +826,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
 static int access(rdv_handle h, int what, const double* in, double* out, float* out_f32, void* stream) {
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(access_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, what, in, out, out_f32);
-  else hipLaunchKernelGGL(access_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, h->ws, h->n, what, in, out, out_f32);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(access_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
+  else hipLaunchKernelGGL(access_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
