@@ -204,7 +204,7 @@ def main():
                        "launch": "hip-graph replay" if use_graph else "eager ctypes", "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": ("rdv::step_kernel_split" if n <= 131072 else "rdv::step_kernel") +
+                         "kernel": ("rdv::step_kernel_split" if n <= 98304 else "rdv::step_kernel") +
                                    ("<float,false>" if args.storage == "f32" else "<double,false>"), "launch_us": launch_us,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n},
             "episodes_finished": stats["episodes"],

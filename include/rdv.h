@@ -58,11 +58,11 @@ typedef enum RdvOnDone {
 } RdvOnDone;
 
 /* Which step kernel rdv_step launches.  Both give the same results (same arithmetic); they differ in how the work of a
- * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 131072) and FUSED above. */
+ * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 98304) and FUSED above. */
 typedef enum RdvKernelVariant {
   RDV_VARIANT_AUTO = 0,
   RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs, resets run divergently in-lane */
-  RDV_VARIANT_SPLIT = 2   /* step waves + service waves (next initial states, statistics, observation stores) */
+  RDV_VARIANT_SPLIT = 2   /* step waves + service waves that precompute every env's next initial state beside them */
 } RdvKernelVariant;
 
 /*

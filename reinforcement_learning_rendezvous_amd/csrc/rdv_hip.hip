@@ -31,7 +31,7 @@ constexpr int kBlock = 256;             // 4 waves per workgroup
 constexpr int kWave = 64;
 constexpr int kChunks = 7;
 constexpr int kStatWords = 16;          // 128-byte slot per wave
-constexpr int64_t kSplitAutoMaxEnvs = 131072;   // at most ~2 waves per SIMD of 256 CUs x 4 SIMDs: the chip is not full
+constexpr int64_t kSplitAutoMaxEnvs = 98304;    // measured crossover (tools/n_sweep.py): split wins while the chip is not full
 enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
        ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
 
