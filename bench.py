@@ -230,6 +230,38 @@ def main():
         out["policy_rollout"] = {"value": n * k2 / pdt, "unit": "env steps/s", "steps": k2,
                                  "policy": "MlpPolicy 17-64-64-6 tanh, stochastic, PyTorch-ROCm fp32 (eager)",
                                  "weights": "tests/golden/mlp_policy.npz" if os.path.exists(npz) else "random init"}
+        # the same rollout step (policy forward + Gaussian sample + clip + env step) captured once in a HIP graph: the
+        # ~10 small PyTorch kernels of the policy stop being paced by the Python interpreter
+        try:
+            g = torch.cuda.CUDAGraph()
+            obs_buf = env.obs              # the env writes its observations in place: the graph reads where it wrote
+            with torch.cuda.graph(g):
+                for _ in range(16):
+                    env.step(pol.act(obs_buf, deterministic=False))
+            torch.cuda.synchronize()
+            g.replay()
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            for _ in range(k2 // 16):
+                g.replay()
+            torch.cuda.synchronize()
+            pdt = time.perf_counter() - p0
+            out["policy_rollout"]["graph_value"] = n * k2 / pdt
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            out["policy_rollout"]["graph_error"] = repr(exc)
+        # the SB3-facing NumPy boundary (actions H2D, obs/reward/done D2H, infos) — PCIe-inclusive, never the bench value
+        from reinforcement_learning_rendezvous_amd.vec_env import RendezvousVecEnv
+        vec = RendezvousVecEnv(n, engine=env)
+        a_np = ring[0].cpu().numpy()
+        vec.reset()
+        for _ in range(3):
+            vec.step(a_np)
+        p0 = time.perf_counter()
+        kv = 20
+        for _ in range(kv):
+            vec.step(a_np)
+        out["vecenv_numpy_boundary"] = {"value": n * kv / (time.perf_counter() - p0), "unit": "env steps/s", "steps": kv,
+                                        "note": "RendezvousVecEnv.step with NumPy actions in, NumPy obs/reward/done + infos out"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)

@@ -1,0 +1,78 @@
+"""
+GPU tests (run with `-m gpu`) of the episode-level evaluation and of the in-kernel reset distribution.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from oracle_engine import OracleEngine
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _policy():
+    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+    return MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+
+
+def test_evaluate_policy_on_gpu_matches_oracle_engine():
+    """custom_callbacks.evaluate_policy batched: HIP engine vs the CPU oracle behind the same driver, same seeds."""
+    from reinforcement_learning_rendezvous_amd import evaluation as ev
+    from reinforcement_learning_rendezvous_amd.params import make_params
+    p = make_params(t_max=60)
+    n = 200
+    s_gpu, per_gpu = ev.evaluate_policy(_policy(), n_evals=n, params=p, device="cuda:0", storage="f64", seed=9)
+    s_cpu, per_cpu = ev.evaluate_policy_batch(_policy(), OracleEngine(n, p, storage="f64", on_done="halt", seed=9))
+    assert list(s_gpu) == ev.SUMMARY_KEYS
+    # the policy runs on different devices (GEMM order): actions differ in the last float32 bits, so a rare rounded-cosine
+    # flip may move an integer outcome in a few of the 200 episodes
+    assert int((per_gpu["ep_end_times"] != per_cpu["ep_end_times"]).sum()) <= 2
+    assert int((per_gpu["ep_successes"] != per_cpu["ep_successes"]).sum()) <= 4
+    for k in ("ep_rew", "ep_len", "ep_dist", "ep_delta_v", "ep_delta_w", "ep_avg_att_error"):
+        assert s_gpu[k] == pytest.approx(s_cpu[k], rel=5e-3), k
+    assert abs(s_gpu["%_successfull_episodes"] - s_cpu["%_successfull_episodes"]) <= 1.0
+    assert abs(s_gpu["%_collided_episodes"] - s_cpu["%_collided_episodes"]) <= 1.0
+    assert 30 < s_gpu["%_successfull_episodes"] < 80          # the shipped policy succeeds in roughly half of the episodes
+
+
+def test_reset_distribution_moments_on_device():
+    """verification/initial_state_distribution.py: deviation magnitudes are U(0, range) (mean r/2, var r^2/12), directions are
+    cube-normalised (general.py:248-254), quaternions unit; here for the in-kernel Philox resets at full batch size."""
+    from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+    n = 65536
+    env = RendezvousBatch(n, device="cuda:0", storage="f64", seed=2024)
+    env.reset()
+    s = env.get_state().cpu().numpy()
+    p = env.params
+    dev = s[:, 0:3] - np.array([0.0, -10.0, 0.0])
+    mag = np.linalg.norm(dev, axis=1)
+    assert mag.mean() == pytest.approx(p.rc0_range / 2, rel=0.01) and mag.var() == pytest.approx(p.rc0_range ** 2 / 12, rel=0.03)
+    assert mag.max() <= p.rc0_range
+    vmag = np.linalg.norm(s[:, 3:6], axis=1)
+    assert vmag.mean() == pytest.approx(p.vc0_range / 2, rel=0.01)
+    # direction: components of a cube-normalised vector are symmetric, |component| has mean 0.5155 (0.5 for a uniform sphere)
+    d = dev / mag[:, None]
+    assert abs(d.mean(axis=0)).max() < 0.01
+    assert np.abs(d).mean() == pytest.approx(0.5155, abs=0.004)
+    for sl, rng in ((slice(6, 10), p.qc0_range), (slice(13, 17), p.qt0_range)):
+        q = s[:, sl]
+        np.testing.assert_allclose(np.linalg.norm(q, axis=1), 1.0, atol=1e-12)
+        ang = 2 * np.arccos(np.clip(q[:, 0], -1, 1))
+        assert ang.mean() == pytest.approx(rng / 2, rel=0.01) and ang.max() <= rng * (1 + 1e-9)
+    assert np.linalg.norm(s[:, 17:20], axis=1).mean() == pytest.approx(p.wt0_range / 2, rel=0.01)
+    # second episode of the same envs: fresh, independent draws
+    a = torch.zeros((n, 6), device="cuda:0")
+    first = s.copy()
+    for _ in range(130):
+        env.step(a)
+    s2 = env.get_state().cpu().numpy()
+    assert np.abs(s2[:, 13:17] - first[:, 13:17]).max(axis=1).min() > 0      # every env has moved to another target attitude
+    # same seed -> same initial states; another seed -> different
+    e2 = RendezvousBatch(1024, device="cuda:0", storage="f64", seed=2024)
+    e3 = RendezvousBatch(1024, device="cuda:0", storage="f64", seed=2025)
+    e2.reset(); e3.reset()
+    np.testing.assert_array_equal(e2.get_state().cpu().numpy(), first[:1024])
+    assert not np.array_equal(e3.get_state().cpu().numpy(), first[:1024])

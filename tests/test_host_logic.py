@@ -215,3 +215,100 @@ def test_two_rank_sharding_equals_single_process():
     assert ref["episodes"] > 50
     np.testing.assert_array_equal(cols["lo"], np.repeat([0, 48], 48))
     np.testing.assert_allclose(cols["ret"], single.get_aux()[:, 6].numpy(), rtol=0, atol=0)
+
+
+# ---------------------------------------------------------------------------------------------- evaluation (f-3)
+def _scalar_evaluate_policy(pol, params, n_evals, seed):
+    """custom_callbacks.py:186-300 written out episode by episode (one single-env engine per episode), as the reference does."""
+    cols = {k: [] for k in ("rew", "end", "dist", "dv", "dw", "succ", "collp", "tfirst", "minpos", "avgatt")}
+    ncoll = nsucc = 0
+    for i in range(n_evals):
+        env = OracleEngine(1, params, storage="f32", on_done="halt", seed=seed, env_id_offset=i)
+        obs = env.reset()
+        d = env.diagnose().numpy()[0]
+        total, sum_att = 0.0, d[2]
+        if d[4] > 0:
+            collisions, t_first, min_pos = 1, 0.0, np.nan
+        else:
+            collisions, t_first, min_pos = 0, np.nan, d[0]
+        done, k = False, 0
+        while not done:
+            k += 1
+            a = pol.act(obs, deterministic=True)
+            obs, r, dn = env.step(a, diag=True)
+            done = bool(dn[0])
+            dg = env.diag.numpy()[0]
+            total += float(r[0])
+            sum_att += dg[2]
+            if dg[4] > 0:
+                collisions += 1
+                if np.isnan(t_first):
+                    t_first = round(k * params.dt, 3)
+            elif np.isnan(t_first):
+                min_pos = min(min_pos, dg[0])
+        aux, st = env.get_aux().numpy()[0], env.get_state().numpy()[0]
+        steps = aux[0] / params.dt
+        for key, v in zip(cols, (total, aux[0], np.linalg.norm(st[0:3]), aux[4], aux[5], aux[3], collisions / steps * 100,
+                                  t_first, min_pos, sum_att / (steps + 1))):
+            cols[key].append(v)
+        ncoll += int(collisions > 0)
+        nsucc += int(aux[3] > 0)
+    return {k: np.array(v) for k, v in cols.items()}, ncoll, nsucc
+
+
+def test_evaluate_policy_batch_equals_the_serial_reference_loop():
+    from reinforcement_learning_rendezvous_amd import evaluation as ev
+    torch.set_num_threads(1)
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    p = make_params(t_max=60)
+    n = 24
+    env = OracleEngine(n, p, storage="f32", on_done="halt", seed=77)
+    summary, per = ev.evaluate_policy_batch(pol, env)
+    ref, ncoll, nsucc = _scalar_evaluate_policy(pol, p, n, 77)
+    assert list(summary) == ev.SUMMARY_KEYS
+    # (the batched policy GEMM and the per-episode GEMV differ in the last float32 bits of the actions: 1e-5-level tolerances)
+    np.testing.assert_allclose(per["ep_rews"], ref["rew"], rtol=1e-4)
+    np.testing.assert_array_equal(per["ep_end_times"], ref["end"])
+    np.testing.assert_allclose(per["ep_dists"], ref["dist"], rtol=1e-4)
+    np.testing.assert_array_equal(per["ep_successes"], ref["succ"])
+    np.testing.assert_allclose(per["ep_collision_percentages"], ref["collp"], rtol=1e-12)
+    np.testing.assert_array_equal(per["ep_times_of_first_collision"], ref["tfirst"])
+    np.testing.assert_allclose(per["ep_min_pos_errors"], ref["minpos"], rtol=1e-4)
+    np.testing.assert_allclose(per["ep_avg_att_errors"], ref["avgatt"], rtol=1e-4)
+    assert summary["%_collided_episodes"] == pytest.approx(ncoll / n * 100)
+    assert summary["%_successfull_episodes"] == pytest.approx(nsucc / n * 100)
+    assert summary["ep_rew"] == pytest.approx(ref["rew"].mean(), rel=1e-4)
+    assert summary["ep_len"] == pytest.approx(ref["end"].mean())
+    assert 0 < summary["ep_len"] <= 60 and summary["ep_success"] >= 0
+
+
+def test_record_trajectories_layout_and_consistency(tmp_path):
+    from reinforcement_learning_rendezvous_amd import evaluation as ev
+    import pickle
+    torch.set_num_threads(1)
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    p = mc.make_eval_params()
+    ics = load_golden("mc_initial_conditions.npz")["states"][:6].copy()
+    ics[:, 6:10] /= np.linalg.norm(ics[:, 6:10], axis=1, keepdims=True)
+    ics[:, 13:17] /= np.linalg.norm(ics[:, 13:17], axis=1, keepdims=True)
+    env = OracleEngine(6, p, storage="f64", on_done="halt")
+    recs = ev.record_trajectories(pol, env, initial_states=ics)
+    g = load_golden("steps_B_mc_policy.npz")          # the same six trajectories recorded from the reference
+    for i, rec in enumerate(recs):
+        L = rec["t"].shape[1]
+        assert rec["rc"].shape == (3, L) and rec["qc"].shape == (4, L) and rec["a"].shape == (6, L)
+        assert rec["rew"].shape == (1, L) and rec["errors"].shape == (4, L)
+        assert np.isnan(rec["rew"][0, 0]) and np.isnan(rec["a"][:, L - 1]).all()      # :81-82 first state / last obs
+        np.testing.assert_array_equal(rec["rc"][:, 0], ics[i, 0:3])
+        valid = g["valid"][:, i].astype(bool)
+        assert L == int(valid.sum()) + 1
+        np.testing.assert_allclose(rec["rc"][:, 1:].T, g["state"][valid, i, 0:3], rtol=0, atol=1e-5)
+        np.testing.assert_allclose(rec["errors"][:, 1:].T, g["diag"][valid, i, 0:4], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(rec["t"][0], np.arange(L) * p.dt)
+        assert rec["collisions"] == int(g["diag0"][i, 4] + g["diag"][valid, i, 4].sum())
+        assert rec["dt"] == 1 and rec["t_max"] == 60 and rec["koz_radius"] == 5 and rec["process_action"] is None
+    path = ev.save_trajectory(recs[0], str(tmp_path))
+    assert os.path.basename(path) == "rdv_data00.pickle"
+    with open(path, "rb") as f:
+        back = pickle.load(f)                          # our own file
+    np.testing.assert_array_equal(back["qt"], recs[0]["qt"])
