@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of the all-core CPU sample")
     ap.add_argument("--no-policy", action="store_true", help="skip the informational MLP-policy rollout leg")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip timing the RCCL gather of rollouts to rank 0")
+    # rehearsal of the N>1 path on a box with ONE GPU (not a measurement): all ranks on cuda:0, collectives over gloo on the host
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
+    ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
     return ap.parse_args()
 
 
@@ -101,11 +104,16 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.shared_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    coll_device = device if args.backend == "nccl" else torch.device("cpu")   # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)       # RCCL over xGMI
+        else:
+            dist.init_process_group("gloo")
 
     n, K, W = args.envs_per_gpu, args.steps, args.warmup
     env = RendezvousBatch(n, device=device, storage=args.storage, seed=0, env_id_offset=rank * n)
@@ -161,7 +169,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     launch_us = ev0.elapsed_time(ev1) * 1e3 / K
@@ -173,12 +181,12 @@ def main():
     if world > 1 and not args.no_gather:
         bufs = None
         if rank == 0:
-            bufs = [[torch.empty_like(x) for _ in range(world)] for x in (env.obs, env.reward, env.done)]
+            bufs = [[torch.empty_like(x, device=coll_device) for _ in range(world)] for x in (env.obs, env.reward, env.done)]
         for it in range(25):
             if it == 5:
                 torch.cuda.synchronize(); dist.barrier(); g0 = time.perf_counter()
             for j, x in enumerate((env.obs, env.reward, env.done)):
-                dist.gather(x, bufs[j] if rank == 0 else None, dst=0)
+                dist.gather(x.to(coll_device), bufs[j] if rank == 0 else None, dst=0)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - g0) / 20 * 1e3
 
@@ -201,7 +209,9 @@ def main():
             "config": {"workload": f"BASELINE config 4 per-GPU shard / config 3 env count: {n} envs per GPU, "
                                    "U(-1,1) float32 actions resident in HBM, default env parameters, in-kernel auto-reset",
                        "envs_per_gpu": n, "global_envs": n * world, "state_storage": args.storage,
-                       "launch": "hip-graph replay" if use_graph else "eager ctypes", "parallelism": f"env-shard x{world}"},
+                       "launch": "hip-graph replay" if use_graph else "eager ctypes", "parallelism": f"env-shard x{world}",
+                       **({"rehearsal": "ranks share cuda:0, gloo collectives: NOT a multi-GPU measurement"}
+                          if (args.shared_gpu or args.backend != "nccl") else {})},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("rdv::step_kernel_split" if n <= 98304 else "rdv::step_kernel") +
