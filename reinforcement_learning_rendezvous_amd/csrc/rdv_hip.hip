@@ -58,18 +58,30 @@ __device__ __forceinline__ void load_env(const typename Vec4<ST>::type* __restri
   e.wt[0] = c6.x; e.wt[1] = c6.y; e.wt[2] = c6.z;
 }
 
+// registers -> the seven storage chunks of one env
+template <typename ST>
+__device__ __forceinline__ void pack_env(const Env& e, typename Vec4<ST>::type* c) {
+  const ST t = ST(0);
+  c[0].x = (ST)e.rc[0]; c[0].y = (ST)e.rc[1]; c[0].z = (ST)e.rc[2]; c[0].w = (ST)e.vc[0];
+  c[1].x = (ST)e.vc[1]; c[1].y = (ST)e.vc[2]; c[1].z = (ST)e.wc[0]; c[1].w = (ST)e.wc[1];
+  c[2].x = (ST)e.wc[2]; c[2].y = (ST)e.bubble; c[2].z = (ST)e.sum_dv; c[2].w = (ST)e.sum_dw;
+  c[3].x = (ST)e.qc[0]; c[3].y = (ST)e.qc[1]; c[3].z = (ST)e.qc[2]; c[3].w = (ST)e.qc[3];
+  c[4].x = (ST)e.qt[0]; c[4].y = (ST)e.qt[1]; c[4].z = (ST)e.qt[2]; c[4].w = (ST)e.qt[3];
+  c[5].x = (ST)e.ep_ret; c[5].y = u2s((uint32_t)e.k, t); c[5].z = u2s(e.flags, t); c[5].w = u2s(e.episode, t);
+  c[6].x = (ST)e.wt[0]; c[6].y = (ST)e.wt[1]; c[6].z = (ST)e.wt[2]; c[6].w = ST(0);
+}
+template <typename ST>
+__device__ __forceinline__ void store_chunks(typename Vec4<ST>::type* __restrict__ ws, int64_t n, int64_t i,
+                                             const typename Vec4<ST>::type* c, bool with_wt) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) ws[k * n + i] = c[k];
+  if (with_wt) ws[6 * n + i] = c[6];
+}
 template <typename ST>
 __device__ __forceinline__ void store_env(typename Vec4<ST>::type* __restrict__ ws, int64_t n, int64_t i, const Env& e, bool with_wt) {
-  using V = typename Vec4<ST>::type;
-  const ST t = ST(0);
-  V c;
-  c.x = (ST)e.rc[0]; c.y = (ST)e.rc[1]; c.z = (ST)e.rc[2]; c.w = (ST)e.vc[0]; ws[0 * n + i] = c;
-  c.x = (ST)e.vc[1]; c.y = (ST)e.vc[2]; c.z = (ST)e.wc[0]; c.w = (ST)e.wc[1]; ws[1 * n + i] = c;
-  c.x = (ST)e.wc[2]; c.y = (ST)e.bubble; c.z = (ST)e.sum_dv; c.w = (ST)e.sum_dw; ws[2 * n + i] = c;
-  c.x = (ST)e.qc[0]; c.y = (ST)e.qc[1]; c.z = (ST)e.qc[2]; c.w = (ST)e.qc[3]; ws[3 * n + i] = c;
-  c.x = (ST)e.qt[0]; c.y = (ST)e.qt[1]; c.z = (ST)e.qt[2]; c.w = (ST)e.qt[3]; ws[4 * n + i] = c;
-  c.x = (ST)e.ep_ret; c.y = u2s((uint32_t)e.k, t); c.z = u2s(e.flags, t); c.w = u2s(e.episode, t); ws[5 * n + i] = c;
-  if (with_wt) { c.x = (ST)e.wt[0]; c.y = (ST)e.wt[1]; c.z = (ST)e.wt[2]; c.w = ST(0); ws[6 * n + i] = c; }
+  typename Vec4<ST>::type c[7];
+  pack_env<ST>(e, c);
+  store_chunks<ST>(ws, n, i, c, with_wt);
 }
 
 // Diagnostic build only (-DRDV_STAMPS, tools/stamp_profile.py): s_memtime stamps at the phase boundaries of the split
@@ -401,9 +413,10 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     __syncthreads();
   } else {
     // ------------------------------------------------------------------ service waves
-    Env ne;
+    V packed[7];               // the next initial state, already in storage layout: nothing is left to compute after the barrier
     float robs[RDV_OBS_DIM];
     if (resets && active) {
+      Env ne;
       const V c5 = ws[5 * n + i];
       ne.episode = s2u(c5.w);
       RDV_STAMP(1);
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
       reset_aux<ST>(P, ne);
       observation(P, ne, robs);
+      pack_env<ST>(ne, packed);
       RDV_STAMP(2);
     }
     RDV_STAMP(3);
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
       if (active && ((m_reset >> lane) & 1ull)) {
         // auto-reset (SB3 DummyVecEnv semantics): the new state to HBM, the first observation of the next episode into the row
-        store_env<ST>(ws, n, i, ne, true);
+        store_chunks<ST>(ws, n, i, packed, true);
 #pragma unroll
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
       }
