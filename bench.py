@@ -227,38 +227,46 @@ def main():
         from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
         npz = os.path.join(ROOT, "tests", "golden", "mlp_policy.npz")
         pol = (MlpPolicy.from_npz(npz) if os.path.exists(npz) else MlpPolicy()).to(device)
-        obs = env.reset()
         k2 = 256
-        for _ in range(16):
-            obs, _, _ = env.step(pol.act(obs, deterministic=False))
-        torch.cuda.synchronize()
-        p0 = time.perf_counter()
-        for _ in range(k2):
-            obs, _, _ = env.step(pol.act(obs, deterministic=False))
-        torch.cuda.synchronize()
-        pdt = time.perf_counter() - p0
-        out["policy_rollout"] = {"value": n * k2 / pdt, "unit": "env steps/s", "steps": k2,
-                                 "policy": "MlpPolicy 17-64-64-6 tanh, stochastic, PyTorch-ROCm fp32 (eager)",
-                                 "weights": "tests/golden/mlp_policy.npz" if os.path.exists(npz) else "random init"}
-        # the same rollout step (policy forward + Gaussian sample + clip + env step) captured once in a HIP graph: the
-        # ~10 small PyTorch kernels of the policy stop being paced by the Python interpreter
-        try:
-            g = torch.cuda.CUDAGraph()
-            obs_buf = env.obs              # the env writes its observations in place: the graph reads where it wrote
-            with torch.cuda.graph(g):
-                for _ in range(16):
-                    env.step(pol.act(obs_buf, deterministic=False))
+        act_buf = torch.empty((n, 6), dtype=torch.float32, device=device)
+
+        def rollout_rate(backend, graph):
+            """env steps/s of [policy forward + Gaussian sample + clip] -> [env step], eager or replayed from a HIP graph"""
+            pol.backend = backend
+            obs = env.reset()
+            step = (lambda: env.step(pol.act(env.obs, deterministic=False, out=act_buf))) if backend == "hip" else \
+                   (lambda: env.step(pol.act(env.obs, deterministic=False)))
+            for _ in range(16):
+                step()
             torch.cuda.synchronize()
-            g.replay()
+            if graph:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    for _ in range(16):
+                        step()
+                torch.cuda.synchronize()
+                g.replay()
+                run = lambda: [g.replay() for _ in range(k2 // 16)]
+            else:
+                run = lambda: [step() for _ in range(k2)]
             torch.cuda.synchronize()
             p0 = time.perf_counter()
-            for _ in range(k2 // 16):
-                g.replay()
+            run()
             torch.cuda.synchronize()
-            pdt = time.perf_counter() - p0
-            out["policy_rollout"]["graph_value"] = n * k2 / pdt
-        except Exception as exc:  # pragma: no cover - depends on the runtime
-            out["policy_rollout"]["graph_error"] = repr(exc)
+            del obs
+            return n * k2 / (time.perf_counter() - p0)
+
+        out["policy_rollout"] = {"unit": "env steps/s", "steps": k2,
+                                 "policy": "MlpPolicy 17-64-64-6 tanh, stochastic (mean + exp(log_std) N(0,1), clipped), fp32",
+                                 "weights": "tests/golden/mlp_policy.npz" if os.path.exists(npz) else "random init"}
+        for key, backend, graph in (("torch_eager", "torch", False), ("torch_graph", "torch", True),
+                                    ("hip_kernel_eager", "hip", False), ("hip_kernel_graph", "hip", True)):
+            try:
+                out["policy_rollout"][key] = rollout_rate(backend, graph)
+            except Exception as exc:  # pragma: no cover - depends on the runtime
+                out["policy_rollout"][key + "_error"] = repr(exc)
+        out["policy_rollout"]["value"] = max(v for k_, v in out["policy_rollout"].items() if isinstance(v, float))
+        pol.close()
         # the SB3-facing NumPy boundary (actions H2D, obs/reward/done D2H, infos) — PCIe-inclusive, never the bench value
         from reinforcement_learning_rendezvous_amd.vec_env import RendezvousVecEnv
         vec = RendezvousVecEnv(n, engine=env)

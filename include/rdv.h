@@ -200,6 +200,20 @@ int rdv_get_stats(rdv_handle h, RdvStats* out_host, int reset, void* stream);
 
 int64_t rdv_num_envs(rdv_handle h);
 
+/*
+ * The actor of the reference's shipped checkpoint (SB3 MlpPolicy, 17-64-64-6, tanh; models/mlp_model_best.zip -> policy.pth,
+ * built by main.py:36-46) as one kernel: actions = clip(mean(obs) [+ exp(log_std) * N(0,1)], -1, 1), the form SB3's
+ * collect_rollouts / predict apply before every env.step.  Weights are HOST pointers in SB3's layout (nn.Linear [out, in]):
+ * w1 [64,17], b1 [64], w2 [64,64], b2 [64], w3 [6,64], b3 [6], log_std [6].  obs [n,17] and actions [n,6] are device pointers.
+ * Noise is Philox4x32-10 keyed by (seed, env_id_offset + i, counter): pass the step index as `counter`.
+ */
+typedef struct RdvPolicyNet* rdv_policy;
+int rdv_policy_create(const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host,
+                      const float* w3_host, const float* b3_host, const float* log_std_host, int device, rdv_policy* out);
+int rdv_policy_destroy(rdv_policy p);
+int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, int deterministic, uint64_t seed,
+                   uint64_t counter, uint64_t env_id_offset, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

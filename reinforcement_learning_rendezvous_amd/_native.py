@@ -26,7 +26,7 @@ SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_va
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
            "rdv_set_kernel_variant",
            "rdv_reset", "rdv_step", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_observe", "rdv_diagnose",
-           "rdv_get_stats", "rdv_num_envs"]
+           "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act"]
 
 
 class RdvError(RuntimeError):
@@ -57,7 +57,7 @@ class Stats(C.Structure):
 
 def build(force=False, quiet=True):
     """Compile csrc/rdv_hip.hip for gfx950 into librdv_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("rdv_hip.hip", "rdv_device.h")] + \
+    srcs = [os.path.join(CSRC, f) for f in ("rdv_hip.hip", "rdv_device.h", "rdv_policy.h")] + \
            [os.path.join(_PKG, "..", "include", "rdv.h")]
     if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
         return LIB_PATH
@@ -102,6 +102,9 @@ def lib():
         "rdv_diagnose": (C.c_int, [vp, vp, vp]),
         "rdv_get_stats": (C.c_int, [vp, C.POINTER(Stats), C.c_int, vp]),
         "rdv_num_envs": (i64, [vp]),
+        "rdv_policy_create": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]),
+        "rdv_policy_destroy": (C.c_int, [vp]),
+        "rdv_policy_act": (C.c_int, [vp, vp, vp, i64, C.c_int, u64, u64, u64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

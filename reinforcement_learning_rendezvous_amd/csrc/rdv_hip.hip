@@ -13,6 +13,7 @@
 // One launch per timestep: rdv_step -> step_kernel fuses impulse, CW propagation, both attitude updates, the
 // collision/success latches, observation, termination, reward, episode statistics and the in-kernel auto-reset.
 #include "rdv_device.h"
+#include "rdv_policy.h"
 
 #include <hip/hip_runtime.h>
 
@@ -686,6 +687,65 @@ int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
 }
 
 int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The shipped actor (SB3 MlpPolicy 17-64-64-6 tanh) as one kernel: see csrc/rdv_policy.h
+struct RdvPolicyNet {
+  uint32_t magic;
+  int device;
+  float* weights;   // device, kPolFloats floats in the packed k-major layout
+};
+static constexpr uint32_t kPolicyMagic = 0x52445650u;   // "RDVP"
+
+int rdv_policy_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* log_std, int device, rdv_policy* out) {
+  if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !log_std || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create: null argument");
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RDV_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
+  if (device < 0 || device >= count) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create: device %d out of range [0,%d)", device, count);
+  DeviceGuard guard(device);
+  std::vector<float> packed((size_t)kPolFloats, 0.0f);
+  // SB3 stores nn.Linear weights as [out, in]; the kernel wants them k-major ([in][out]) so that one input's 64 weights are contiguous
+  for (int j = 0; j < kPolHid; ++j) for (int k = 0; k < kPolIn; ++k) packed[kPolW1 + k * kPolHid + j] = w1[j * kPolIn + k];
+  for (int j = 0; j < kPolHid; ++j) packed[kPolB1 + j] = b1[j];
+  for (int j = 0; j < kPolHid; ++j) for (int k = 0; k < kPolHid; ++k) packed[kPolW2 + k * kPolHid + j] = w2[j * kPolHid + k];
+  for (int j = 0; j < kPolHid; ++j) packed[kPolB2 + j] = b2[j];
+  for (int j = 0; j < kPolOut; ++j) for (int k = 0; k < kPolHid; ++k) packed[kPolW3 + k * kPolOutPad + j] = w3[j * kPolHid + k];
+  for (int j = 0; j < kPolOut; ++j) { packed[kPolB3 + j] = b3[j]; packed[kPolStd + j] = std::exp(log_std[j]); }
+  RdvPolicyNet* p = new (std::nothrow) RdvPolicyNet();
+  if (!p) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_policy_create: host allocation failed");
+  p->magic = kPolicyMagic; p->device = device; p->weights = nullptr;
+  hipError_t err = hipMalloc(&p->weights, packed.size() * sizeof(float));
+  if (err == hipSuccess) err = hipMemcpy(p->weights, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
+  // the kernel keeps the weights and 8 activation images in 93 KiB of dynamic LDS (above the 64 KiB default limit)
+  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(policy_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPolLdsBytes);
+  if (err != hipSuccess) { if (p->weights) (void)hipFree(p->weights); delete p; return fail(RDV_ERR_HIP, "rdv_policy_create: %s", hipGetErrorString(err)); }
+  *out = p;
+  return RDV_OK;
+}
+
+int rdv_policy_destroy(rdv_policy p) {
+  if (!p || p->magic != kPolicyMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_policy");
+  DeviceGuard guard(p->device);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(p->weights);
+  p->magic = 0;
+  delete p;
+  return RDV_OK;
+}
+
+int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, int deterministic, uint64_t seed, uint64_t counter,
+                   uint64_t env_id_offset, void* stream) {
+  if (!p || p->magic != kPolicyMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_policy");
+  if (!obs || !actions || n <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_act: obs, actions and a positive n are required");
+  if ((reinterpret_cast<uintptr_t>(obs) & 15) || (reinterpret_cast<uintptr_t>(actions) & 15))
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_act: obs and actions must be 16-byte aligned");
+  DeviceGuard guard(p->device);
+  hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((n + kPolBlockEnvs - 1) / kPolBlockEnvs)), dim3(kPolBlock), kPolLdsBytes, static_cast<hipStream_t>(stream),
+                     p->weights, obs, actions, n, deterministic, seed, counter, env_id_offset);
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
+}
 
 int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage, int on_done, uint64_t seed,
                uint64_t env_id_offset, void* workspace, rdv_handle* out) {

@@ -2,8 +2,11 @@
 The SB3 MlpPolicy actor of the reference's shipped checkpoint (models/mlp_model_best.zip -> policy.pth):
 ``a = clip(W3 tanh(W2 tanh(W1 obs + b1) + b2) + b3, -1, 1)``, 17-64-64-6, float32, plus the stochastic rollout form
 ``a = clip(mean + exp(log_std) * N(0,1), -1, 1)`` that SB3's collect_rollouts uses (main.py:33-46 builds it with
-``activation_fn=Tanh``).  Runs in PyTorch on whatever device the observations live on; it is not part of the env kernel.
+``activation_fn=Tanh``).  It is not part of the env kernel.  On the GPU the forward pass is ONE hand-written HIP kernel
+(csrc/rdv_policy.h, through the C ABI: rdv_policy_act); ``backend="torch"`` keeps the plain PyTorch modules (any device),
+which the tests use as the reference of that kernel.
 """
+import ctypes as C
 import io
 import zipfile
 
@@ -15,8 +18,12 @@ _KEYS = ["mlp_extractor.policy_net.0.weight", "mlp_extractor.policy_net.0.bias",
 
 
 class MlpPolicy(torch.nn.Module):
-    def __init__(self, weights=None, obs_dim=17, hidden=64, act_dim=6, seed=0):
+    def __init__(self, weights=None, obs_dim=17, hidden=64, act_dim=6, seed=0, backend="auto"):
         super().__init__()
+        self.backend = backend          # "auto": HIP kernel for CUDA observations, PyTorch otherwise; "torch"; "hip"
+        self.noise_seed = int(seed)     # HIP backend: Philox key of the exploration noise; the call counter is the step index
+        self._hip = {}                  # device index -> rdv_policy handle
+        self._calls = 0
         self.l1 = torch.nn.Linear(obs_dim, hidden)
         self.l2 = torch.nn.Linear(hidden, hidden)
         self.l3 = torch.nn.Linear(hidden, act_dim)
@@ -53,9 +60,46 @@ class MlpPolicy(torch.nn.Module):
     def mean(self, obs):
         return self.l3(torch.tanh(self.l2(torch.tanh(self.l1(obs)))))
 
+    def _hip_handle(self, device):
+        from . import _native as N
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        if idx not in self._hip:
+            w = [t.detach().to("cpu", torch.float32).contiguous() for t in
+                 (self.l1.weight, self.l1.bias, self.l2.weight, self.l2.bias, self.l3.weight, self.l3.bias, self.log_std)]
+            h = C.c_void_p()
+            N.check(N.lib().rdv_policy_create(*[C.c_void_p(t.data_ptr()) for t in w], idx, C.byref(h)))
+            self._hip[idx] = h
+        return self._hip[idx]
+
+    def _act_hip(self, obs, deterministic, out=None):
+        from . import _native as N
+        obs = obs.contiguous()
+        n = obs.shape[0]
+        if out is None:
+            out = torch.empty((n, 6), dtype=torch.float32, device=obs.device)
+        stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
+        N.check(N.lib().rdv_policy_act(self._hip_handle(obs.device), C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()), n,
+                                       int(bool(deterministic)), C.c_uint64(self.noise_seed), C.c_uint64(self._calls),
+                                       C.c_uint64(0), stream))
+        self._calls += 1
+        return out
+
+    def close(self):
+        if self._hip:
+            from . import _native as N
+            for h in self._hip.values():
+                N.lib().rdv_policy_destroy(h)
+            self._hip = {}
+
     @torch.no_grad()
-    def act(self, obs, deterministic=True, generator=None):
+    def act(self, obs, deterministic=True, generator=None, out=None):
         """SB3 ``predict``: the distribution mean (or a sample), clipped to the action Box."""
+        hip = self.backend == "hip" or (self.backend == "auto" and obs.is_cuda and obs.dtype == torch.float32
+                                        and obs.dim() == 2 and obs.shape[1] == 17)
+        if hip:
+            if generator is not None:
+                self.noise_seed = int(generator.initial_seed())
+            return self._act_hip(obs, deterministic, out)
         a = self.mean(obs)
         if not deterministic:
             noise = torch.randn(a.shape, dtype=a.dtype, device=a.device, generator=generator)
