@@ -178,6 +178,35 @@ int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth);
 /* Tuning: force a kernel variant (RdvKernelVariant).  Results do not depend on it. */
 int rdv_set_kernel_variant(rdv_handle h, int variant);
 
+/*
+ * Rigid-body attributes of the env: self.inertia (rendezvous_env.py:75-79), self.inertia_target (:96-100) — row-major 3x3, body
+ * frame — and the constant body torques handed to integrate_chaser_attitude / integrate_target_attitude (:552, :579; step()
+ * passes zeros, :181, :184).  The reference constructor hard-codes 16.67 * Identity for both bodies; its right-hand side
+ * (utils/dynamics.py:93-175) and its integrator (scipy solve_ivp RK45, rtol 1e-7, atol 1e-6, :561-570) are general, and the
+ * attributes can be overwritten after construction.  The inverses (self.inv_inertia :80, :101) are computed by the library.
+ * max_delta_w (:82, derived from inertia[0][0] in the constructor) is an RdvParams field and is not touched here.
+ */
+typedef enum RdvIntegrator {
+  RDV_INTEGRATOR_AUTO = 0,   /* EXACT when both tensors are c * Identity and both torques are zero, RK45 otherwise */
+  RDV_INTEGRATOR_EXACT = 1,  /* closed form q (x) exp(w dt / 2); refused (RDV_ERR_BAD_PARAMS) when it does not apply */
+  RDV_INTEGRATOR_RK45 = 2    /* the reference's own scheme: Dormand-Prince 5(4) with scipy's step-size control, per env */
+} RdvIntegrator;
+
+typedef struct RdvRigidBody {
+  double inertia_chaser[9];
+  double inertia_target[9];
+  double torque_chaser[3];
+  double torque_target[3];
+  double rtol;               /* :567 1e-7 */
+  double atol;               /* :568 1e-6 */
+  int32_t integrator;        /* RdvIntegrator */
+  int32_t reserved;
+} RdvRigidBody;
+
+int rdv_rigid_body_default(RdvRigidBody* out_host);                    /* the reference constructor's values, AUTO */
+int rdv_set_rigid_body(rdv_handle h, const RdvRigidBody* body_host);   /* synchronises the device, like rdv_set_params */
+int rdv_get_rigid_body(rdv_handle h, RdvRigidBody* out_host);
+
 /* RendezvousEnv.reset() (:223-270) for every env, or for envs with mask[i] != 0.  obs_out [N,17] nullable. */
 int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream);
 

@@ -15,7 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "librdv_oracle.so")
 
 STORAGE_F32, STORAGE_F64 = 0, 1
 ON_DONE_RESET, ON_DONE_HALT, ON_DONE_NOTHING = 0, 1, 2
-INTEGRATOR_EXACT, INTEGRATOR_RK45 = 0, 1
+INTEGRATOR_EXACT, INTEGRATOR_RK45, INTEGRATOR_GENERAL = 0, 1, 2
 
 _PARAM_FIELDS = [
     ("nominal_rc0", 3), ("nominal_vc0", 3), ("nominal_qc0", 4), ("nominal_wc0", 3), ("nominal_qt0", 4),
@@ -48,7 +48,29 @@ class OrcParams(C.Structure):
 
 class OrcConfig(C.Structure):
     _fields_ = [("storage", C.c_int32), ("on_done", C.c_int32), ("integrator", C.c_int32), ("tape_depth", C.c_int32),
-                ("numpy_legacy", C.c_int32), ("reserved", C.c_int32), ("tape", C.c_void_p), ("seed", C.c_uint64), ("env_id_offset", C.c_uint64)]
+                ("numpy_legacy", C.c_int32), ("reserved", C.c_int32), ("tape", C.c_void_p), ("seed", C.c_uint64), ("env_id_offset", C.c_uint64),
+                ("rigid", C.c_void_p)]
+
+
+class OrcRigidBody(C.Structure):
+    """self.inertia / self.inv_inertia (rendezvous_env.py:75-80), the target's (:96-101) and the torque arguments of
+    integrate_*_attitude (:552, :579); rtol/atol of the env's solve_ivp calls (:567-568)."""
+    _fields_ = [("inertia_chaser", C.c_double * 9), ("inv_inertia_chaser", C.c_double * 9), ("torque_chaser", C.c_double * 3),
+                ("inertia_target", C.c_double * 9), ("inv_inertia_target", C.c_double * 9), ("torque_target", C.c_double * 3),
+                ("rtol", C.c_double), ("atol", C.c_double)]
+
+    @classmethod
+    def make(cls, inertia_chaser, inertia_target, torque_chaser=(0, 0, 0), torque_target=(0, 0, 0), rtol=1e-7, atol=1e-6,
+             inv_inertia_chaser=None, inv_inertia_target=None):
+        b = cls()
+        ic = np.asarray(inertia_chaser, np.float64).reshape(3, 3); it = np.asarray(inertia_target, np.float64).reshape(3, 3)
+        iic = np.linalg.inv(ic) if inv_inertia_chaser is None else np.asarray(inv_inertia_chaser, np.float64)   # :80
+        iit = np.linalg.inv(it) if inv_inertia_target is None else np.asarray(inv_inertia_target, np.float64)   # :101
+        b.inertia_chaser[:] = ic.ravel(); b.inv_inertia_chaser[:] = iic.ravel()
+        b.inertia_target[:] = it.ravel(); b.inv_inertia_target[:] = iit.ravel()
+        b.torque_chaser[:] = np.asarray(torque_chaser, np.float64); b.torque_target[:] = np.asarray(torque_target, np.float64)
+        b.rtol, b.atol = rtol, atol
+        return b
 
 
 class OrcStats(C.Structure):
@@ -160,16 +182,37 @@ def att_rhs(y):
     lib().orc_att_rhs(_p(y), _p(dy)); return dy
 
 
+def att_rhs_general(y, inertia, inv_inertia, torque):
+    y = np.ascontiguousarray(y, np.float64); dy = np.empty(7, np.float64)
+    i = np.ascontiguousarray(inertia, np.float64); ii = np.ascontiguousarray(inv_inertia, np.float64)
+    t = np.ascontiguousarray(torque, np.float64)
+    lib().orc_att_rhs_general(_p(y), _p(i), _p(ii), _p(t), _p(dy)); return dy
+
+
+def solve_attitude_rk45(y0, dt, inertia, inv_inertia, torque, rtol=1e-7, atol=1e-6):
+    """The env's solve_ivp(RK45) call (rendezvous_env.py:561-570) -> (y(dt) before the :574 normalisation, nfev)."""
+    y = np.array(y0, np.float64)
+    i = np.ascontiguousarray(inertia, np.float64); ii = np.ascontiguousarray(inv_inertia, np.float64)
+    t = np.ascontiguousarray(torque, np.float64)
+    L = lib(); L.orc_solve_attitude_rk45.restype = C.c_int
+    nfev = L.orc_solve_attitude_rk45(_p(y), C.c_double(dt), _p(i), _p(ii), _p(t), C.c_double(rtol), C.c_double(atol))
+    return y, nfev
+
+
 class OracleBatch:
     """N reference-faithful environments on the CPU (fp64).  Mirrors the rdv_* C ABI one to one."""
 
     def __init__(self, n, params=None, storage=STORAGE_F64, on_done=ON_DONE_RESET, seed=0, env_id_offset=0,
-                 integrator=INTEGRATOR_EXACT, tape=None, n_threads=1, numpy_legacy=False):
+                 integrator=INTEGRATOR_EXACT, tape=None, n_threads=1, numpy_legacy=False, rigid=None):
         self.L = lib()
         self.n = int(n)
         self.params = params if params is not None else default_params()
         self.envs = np.zeros(self.n, ENV_DTYPE)
-        self.cfg = OrcConfig(storage, on_done, integrator, 0, int(numpy_legacy), 0, None, seed, env_id_offset)
+        self.rigid = rigid      # OrcRigidBody: general inertia / torque, integrated with RK45 (INTEGRATOR_GENERAL)
+        if rigid is not None:
+            integrator = INTEGRATOR_GENERAL
+        self.cfg = OrcConfig(storage, on_done, integrator, 0, int(numpy_legacy), 0, None, seed, env_id_offset,
+                             None if rigid is None else C.addressof(rigid))
         self.stats = OrcStats()
         self.n_threads = n_threads
         self._tape = None

@@ -216,14 +216,41 @@ void orc_att_rhs(const double y[7], double dy[7]) {
   for (int i = 0; i < 3; ++i) dy[4 + i] = inv_inertia * (0.0 - cp[i]);
 }
 
-/* Dormand-Prince 5(4) with scipy's step-size control (scipy/integrate/_ivp/rk.py, common.py; public algorithm),
- * rtol=1e-7, atol=1e-6 as rendezvous_env.py:567-568.  Cross-check only. */
+void orc_att_rhs_general(const double y[7], const double inertia[9], const double inv_inertia[9], const double torque[3],
+                         double dy[7]) {
+  /* derivative_of_att_and_rot_rate (dynamics.py:93-119) for any inertia tensor (row-major 3x3) and body torque */
+  const double mag = norm4(y);                        /* dynamics.py:109 */
+  const double q0[4] = {y[0] / mag, y[1] / mag, y[2] / mag, y[3] / mag};
+  const double mag2 = norm4(q0);                      /* dynamics.py:134 (quat_derivative normalises again) */
+  const double q[4] = {q0[0] / mag2, q0[1] / mag2, q0[2] / mag2, q0[3] / mag2};
+  const double w1 = y[4], w2 = y[5], w3 = y[6];
+  dy[0] = 0.5 * (-w1 * q[1] - w2 * q[2] - w3 * q[3]);   /* dynamics.py:137-151 */
+  dy[1] = 0.5 * (w1 * q[0] + w3 * q[2] - w2 * q[3]);
+  dy[2] = 0.5 * (w2 * q[0] - w3 * q[1] + w1 * q[3]);
+  dy[3] = 0.5 * (w3 * q[0] + w2 * q[1] - w1 * q[2]);
+  /* dynamics.py:169-171: w_dot = inv_inertia @ (torque - w x (inertia @ w)) */
+  const double w[3] = {w1, w2, w3};
+  double L[3], cp[3], rhs[3];
+  for (int i = 0; i < 3; ++i) L[i] = inertia[3 * i] * w1 + inertia[3 * i + 1] * w2 + inertia[3 * i + 2] * w3;
+  cross3(w, L, cp);
+  for (int i = 0; i < 3; ++i) rhs[i] = torque[i] - cp[i];
+  for (int i = 0; i < 3; ++i)
+    dy[4 + i] = inv_inertia[3 * i] * rhs[0] + inv_inertia[3 * i + 1] * rhs[1] + inv_inertia[3 * i + 2] * rhs[2];
+}
+
+/* Dormand-Prince 5(4) with scipy's step-size control (scipy/integrate/_ivp/rk.py, common.py; public algorithm), as
+ * solve_ivp(method='RK45', rtol, atol) runs it for rendezvous_env.py:561-570 / :588-597 (rtol=1e-7, atol=1e-6 there).
+ * body == NULL: the env's constant isotropic tensor and zero torque (orc_att_rhs); otherwise the general right-hand side. */
+typedef struct RigidCtx { const double* inertia; const double* inv_inertia; const double* torque; } RigidCtx;
+static void att_rhs(const RigidCtx* body, const double y[7], double dy[7]) {
+  if (body) orc_att_rhs_general(y, body->inertia, body->inv_inertia, body->torque, dy);
+  else orc_att_rhs(y, dy);
+}
 static double rms7(const double* x) {
   double s = 0; for (int i = 0; i < 7; ++i) s += x[i] * x[i];
   return sqrt(s) / sqrt(7.0);
 }
-static void rk45_integrate(double y[7], double t_bound) {
-  static const double C[6] = {0, 1.0 / 5, 3.0 / 10, 4.0 / 5, 8.0 / 9, 1};
+static int rk45_integrate(double y[7], double t_bound, const RigidCtx* body, double rtol, double atol) {
   static const double A[6][5] = {{0, 0, 0, 0, 0},
                                  {1.0 / 5, 0, 0, 0, 0},
                                  {3.0 / 40, 9.0 / 40, 0, 0, 0},
@@ -232,10 +259,9 @@ static void rk45_integrate(double y[7], double t_bound) {
                                  {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
   static const double B[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
   static const double E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
-  const double rtol = 1e-7, atol = 1e-6;
-  (void)C;
   double t = 0, f[7], K[7][7], scale[7], tmp[7];
-  orc_att_rhs(y, f);
+  int nfev = 0, attempts = 0;   /* attempts: accepted + rejected steps; capped (scipy has no cap; 4096 per dt means it is failing) */
+  att_rhs(body, y, f); ++nfev;
   /* select_initial_step, order = 4 */
   double h_abs;
   {
@@ -246,7 +272,7 @@ static void rk45_integrate(double y[7], double t_bound) {
     if (h0 > t_bound) h0 = t_bound;
     double y1[7], f1[7];
     for (int i = 0; i < 7; ++i) y1[i] = y[i] + h0 * f[i];
-    orc_att_rhs(y1, f1);
+    att_rhs(body, y1, f1); ++nfev;
     for (int i = 0; i < 7; ++i) a[i] = (f1[i] - f[i]) / scale[i];
     const double d2 = rms7(a) / h0;
     double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
@@ -268,7 +294,7 @@ static void rk45_integrate(double y[7], double t_bound) {
           for (int j = 0; j < s; ++j) dy += K[j][i] * A[s][j];
           tmp[i] = y[i] + dy * h;
         }
-        orc_att_rhs(tmp, K[s]);
+        att_rhs(body, tmp, K[s]); ++nfev;
       }
       double y_new[7], f_new[7];
       for (int i = 0; i < 7; ++i) {
@@ -276,7 +302,7 @@ static void rk45_integrate(double y[7], double t_bound) {
         for (int s = 0; s < 6; ++s) acc += K[s][i] * B[s];
         y_new[i] = y[i] + h * acc;
       }
-      orc_att_rhs(y_new, f_new);
+      att_rhs(body, y_new, f_new); ++nfev;
       for (int i = 0; i < 7; ++i) K[6][i] = f_new[i];
       double err[7];
       for (int i = 0; i < 7; ++i) {
@@ -286,25 +312,51 @@ static void rk45_integrate(double y[7], double t_bound) {
         err[i] = acc * h / sc;
       }
       const double error_norm = rms7(err);
+      ++attempts;
       if (error_norm < 1) {
         double factor = error_norm == 0 ? 10.0 : fmin(10.0, 0.9 * pow(error_norm, -0.2));
         if (rejected && factor > 1) factor = 1;
         h_abs *= factor;
         t = t_new;
         for (int i = 0; i < 7; ++i) { y[i] = y_new[i]; f[i] = f_new[i]; }
+        if (attempts >= 4096 && t < t_bound) { for (int i = 0; i < 7; ++i) y[i] = NAN; return nfev; }
         break;
       }
+      if (!(error_norm == error_norm) || h_abs <= min_step || attempts >= 4096) {
+        /* scipy gives up here ("step size too small" / non-finite state) and the reference then fails on the empty
+         * solution (rendezvous_env.py:572-574); the restatement poisons the state instead of looping */
+        for (int i = 0; i < 7; ++i) y[i] = NAN;
+        return nfev;
+      }
       h_abs *= fmax(0.2, 0.9 * pow(error_norm, -0.2));
+      if (h_abs < min_step) h_abs = min_step;
       rejected = 1;
     }
   }
+  return nfev;
+}
+
+int orc_solve_attitude_rk45(double y[7], double dt, const double inertia[9], const double inv_inertia[9], const double torque[3],
+                            double rtol, double atol) {
+  const RigidCtx body = {inertia, inv_inertia, torque};
+  return rk45_integrate(y, dt, &body, rtol, atol);
+}
+
+void orc_integrate_attitude_general(double q[4], double w[3], double dt, const double inertia[9], const double inv_inertia[9],
+                                    const double torque[3], double rtol, double atol) {
+  /* rendezvous_env.py:552-604 with self.inertia / self.inv_inertia (or the target's) and the torque argument as given */
+  double y[7] = {q[0], q[1], q[2], q[3], w[0], w[1], w[2]};
+  (void)orc_solve_attitude_rk45(y, dt, inertia, inv_inertia, torque, rtol, atol);
+  const double mag = norm4(y);                                 /* :574, :601 */
+  for (int i = 0; i < 4; ++i) q[i] = y[i] / mag;
+  for (int i = 0; i < 3; ++i) w[i] = y[4 + i];
 }
 
 void orc_integrate_attitude(double q[4], double w[3], double dt, int integrator) {
   /* rendezvous_env.py:552-604: y0=[q,w] -> solve_ivp(RK45) over [0,dt] -> q /= |q| (:574, :601). */
   if (integrator == ORC_INTEGRATOR_RK45) {
     double y[7] = {q[0], q[1], q[2], q[3], w[0], w[1], w[2]};
-    rk45_integrate(y, dt);
+    (void)rk45_integrate(y, dt, NULL, 1e-7, 1e-6);   /* :567-568 */
     const double mag = norm4(y);
     for (int i = 0; i < 4; ++i) q[i] = y[i] / mag;
     for (int i = 0; i < 3; ++i) w[i] = y[4 + i];
@@ -487,8 +539,14 @@ static void step_one(const OrcParams* p, const OrcConfig* c, OrcEnv* e, int64_t 
   memcpy(e->rc, rn, sizeof rn); memcpy(e->vc, vn, sizeof vn);
   for (int j = 0; j < 3; ++j)                                                               /* :173, :180 */
     e->wc[j] = e->wc[j] + (c->numpy_legacy ? (double)dwb32[j] : (double)a32[3 + j] * p->max_delta_w);
-  orc_integrate_attitude(e->qc, e->wc, p->dt, c->integrator);                               /* :181 */
-  orc_integrate_attitude(e->qt, e->wt, p->dt, c->integrator);                               /* :184 */
+  if (c->integrator == ORC_INTEGRATOR_GENERAL && c->rigid) {
+    const OrcRigidBody* b = c->rigid;
+    orc_integrate_attitude_general(e->qc, e->wc, p->dt, b->inertia_chaser, b->inv_inertia_chaser, b->torque_chaser, b->rtol, b->atol); /* :181 */
+    orc_integrate_attitude_general(e->qt, e->wt, p->dt, b->inertia_target, b->inv_inertia_target, b->torque_target, b->rtol, b->atol); /* :184 */
+  } else {
+    orc_integrate_attitude(e->qc, e->wc, p->dt, c->integrator);                             /* :181 */
+    orc_integrate_attitude(e->qt, e->wt, p->dt, c->integrator);                             /* :184 */
+  }
   canon_state(e, c->storage);
 
   if (!e->collided) {                                                                       /* :187-190 */

@@ -59,7 +59,16 @@ typedef struct OrcEnv {
 
 enum { ORC_STORAGE_F32 = 0, ORC_STORAGE_F64 = 1 };
 enum { ORC_ON_DONE_RESET = 0, ORC_ON_DONE_HALT = 1, ORC_ON_DONE_NOTHING = 2 };
-enum { ORC_INTEGRATOR_EXACT = 0, ORC_INTEGRATOR_RK45 = 1 };
+enum { ORC_INTEGRATOR_EXACT = 0, ORC_INTEGRATOR_RK45 = 1, ORC_INTEGRATOR_GENERAL = 2 };
+
+/* The rigid-body attributes of the env (self.inertia / self.inv_inertia :75-80, self.inertia_target / self.inv_inertia_target
+ * :96-101; row-major 3x3) and the torque arguments of integrate_chaser_attitude / integrate_target_attitude (:552, :579).
+ * Used with ORC_INTEGRATOR_GENERAL: scipy's RK45 on the full right-hand side (dynamics.py:93-175). */
+typedef struct OrcRigidBody {
+  double inertia_chaser[9], inv_inertia_chaser[9], torque_chaser[3];
+  double inertia_target[9], inv_inertia_target[9], torque_target[3];
+  double rtol, atol;      /* :567-568: 1e-7, 1e-6 */
+} OrcRigidBody;
 
 typedef struct OrcConfig {
   int32_t storage;        /* ORC_STORAGE_F32 rounds the state/aux to float after every update, as the HIP
@@ -74,6 +83,7 @@ typedef struct OrcConfig {
   const double* tape;     /* [depth][n][20] */
   uint64_t seed;
   uint64_t env_id_offset;
+  const OrcRigidBody* rigid;   /* ORC_INTEGRATOR_GENERAL only */
 } OrcConfig;
 
 typedef struct OrcStats {
@@ -101,6 +111,12 @@ void   orc_cw_solution(const double r0[3], const double v0[3], double n, double 
 double orc_angle_between(const double a[3], const double b[3]);                     /* general.py:163-181 */
 void   orc_integrate_attitude(double q[4], double w[3], double dt, int integrator); /* rendezvous_env.py:552-604 */
 void   orc_att_rhs(const double y[7], double dy[7]);                                /* dynamics.py:93-175 (I = 16.67*1, torque 0) */
+void   orc_att_rhs_general(const double y[7], const double inertia[9], const double inv_inertia[9], const double torque[3],
+                           double dy[7]);                                            /* dynamics.py:93-175, any tensor / torque */
+int    orc_solve_attitude_rk45(double y[7], double dt, const double inertia[9], const double inv_inertia[9],
+                               const double torque[3], double rtol, double atol);    /* the solve_ivp call of :561-570; returns nfev */
+void   orc_integrate_attitude_general(double q[4], double w[3], double dt, const double inertia[9], const double inv_inertia[9],
+                                      const double torque[3], double rtol, double atol);   /* :552-604 incl. the normalisation */
 
 /* env-level pieces */
 void   orc_get_observation(const OrcParams* p, const OrcEnv* e, float obs[17]);    /* :294-311 */

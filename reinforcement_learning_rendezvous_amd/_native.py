@@ -24,7 +24,7 @@ ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVI
 # every symbol include/rdv.h declares (tests/test_abi.py checks the list against the header and the .so)
 SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
-           "rdv_set_kernel_variant",
+           "rdv_set_kernel_variant", "rdv_rigid_body_default", "rdv_set_rigid_body", "rdv_get_rigid_body",
            "rdv_reset", "rdv_step", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_observe", "rdv_diagnose",
            "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act"]
 
@@ -53,6 +53,17 @@ class Stats(C.Structure):
                     collisions=int(self.collisions), reasons=[int(x) for x in self.reasons],
                     sum_return=float(self.sum_return), sum_length=float(self.sum_length),
                     sum_delta_v=float(self.sum_delta_v), sum_delta_w=float(self.sum_delta_w))
+
+
+INTEGRATORS = {"auto": 0, "exact": 1, "rk45": 2}
+
+
+class RigidBody(C.Structure):
+    """RdvRigidBody: self.inertia / self.inertia_target (rendezvous_env.py:75-79, :96-100; row-major 3x3), the body torques
+    of integrate_*_attitude (:552, :579) and the tolerances of the env's solve_ivp calls (:567-568)."""
+    _fields_ = [("inertia_chaser", C.c_double * 9), ("inertia_target", C.c_double * 9), ("torque_chaser", C.c_double * 3),
+                ("torque_target", C.c_double * 3), ("rtol", C.c_double), ("atol", C.c_double),
+                ("integrator", C.c_int32), ("reserved", C.c_int32)]
 
 
 def build(force=False, quiet=True):
@@ -93,6 +104,9 @@ def lib():
         "rdv_seed": (C.c_int, [vp, u64]),
         "rdv_set_reset_tape": (C.c_int, [vp, vp, i32]),
         "rdv_set_kernel_variant": (C.c_int, [vp, C.c_int]),
+        "rdv_rigid_body_default": (C.c_int, [C.POINTER(RigidBody)]),
+        "rdv_set_rigid_body": (C.c_int, [vp, C.POINTER(RigidBody)]),
+        "rdv_get_rigid_body": (C.c_int, [vp, C.POINTER(RigidBody)]),
         "rdv_reset": (C.c_int, [vp, vp, vp, vp]),
         "rdv_step": (C.c_int, [vp, vp, C.POINTER(StepOut), vp]),
         "rdv_set_state": (C.c_int, [vp, vp, vp]),

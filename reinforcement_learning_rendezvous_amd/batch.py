@@ -9,6 +9,7 @@ DummyVecEnv auto-reset (``on_done="reset"``) or monte_carlo.py's stop-at-done (`
 """
 import ctypes as C
 
+import numpy as np
 import torch
 
 from . import _native as N
@@ -165,6 +166,41 @@ class RendezvousBatch:
     def set_params(self, params: EnvParams):
         N.check(self._lib.rdv_set_params(self._h, C.byref(params)))
         self.params = params.copy()
+
+    def set_rigid_body(self, inertia=None, inertia_target=None, torque=None, torque_target=None, integrator=None,
+                       rtol=None, atol=None):
+        """The env attributes ``inertia`` / ``inertia_target`` (rendezvous_env.py:75-79, :96-100; 3x3, or 3 principal moments)
+        and the body torques of ``integrate_chaser_attitude`` / ``integrate_target_attitude`` (:552, :579).  Anything but the
+        constructor's c*Identity / zero torque is integrated per env with the reference's scheme (scipy RK45, rtol 1e-7,
+        atol 1e-6) inside the step kernel; ``integrator`` in {"auto", "exact", "rk45"}.  Arguments left None keep their value."""
+        b = N.RigidBody()
+        N.check(self._lib.rdv_get_rigid_body(self._h, C.byref(b)))
+
+        def tensor(x):
+            x = np.asarray(x, np.float64)
+            return (np.diag(x) if x.shape == (3,) else x.reshape(3, 3)).ravel()
+        if inertia is not None:
+            b.inertia_chaser[:] = tensor(inertia)
+        if inertia_target is not None:
+            b.inertia_target[:] = tensor(inertia_target)
+        if torque is not None:
+            b.torque_chaser[:] = np.asarray(torque, np.float64).reshape(3)
+        if torque_target is not None:
+            b.torque_target[:] = np.asarray(torque_target, np.float64).reshape(3)
+        if integrator is not None:
+            b.integrator = N.INTEGRATORS[integrator]
+        if rtol is not None:
+            b.rtol = float(rtol)
+        if atol is not None:
+            b.atol = float(atol)
+        N.check(self._lib.rdv_set_rigid_body(self._h, C.byref(b)))
+
+    def get_rigid_body(self):
+        b = N.RigidBody()
+        N.check(self._lib.rdv_get_rigid_body(self._h, C.byref(b)))
+        return dict(inertia=np.array(b.inertia_chaser).reshape(3, 3), inertia_target=np.array(b.inertia_target).reshape(3, 3),
+                    torque=np.array(b.torque_chaser), torque_target=np.array(b.torque_target), rtol=b.rtol, atol=b.atol,
+                    integrator={v: k for k, v in N.INTEGRATORS.items()}[b.integrator])
 
     def set_reward_kwargs(self, **kw):
         """The reference passes these to get_bubble_reward on every step (rendezvous_env.py:211, :313)."""

@@ -62,6 +62,10 @@ struct DevParams {
   // reset (rendezvous_env.py:229-258); nominal quaternions pre-normalised (quat_product does it, quaternions.py:159-160)
   double nominal_rc0[3], nominal_vc0[3], nominal_qc0[4], nominal_wc0[3], nominal_qt0[4], nominal_wt0[3];
   double rc0_range, vc0_range, qc0_range, wc0_range, qt0_range, wt0_range;
+  // general rigid bodies (rdv_set_rigid_body; read by the kGeneral kernels only): inertia tensor, its inverse (row-major) and the
+  // constant body torque of the chaser [0] and the target [1]; tolerances of the env's solve_ivp calls (:567-568)
+  double body_inertia[2][9], body_inv_inertia[2][9], body_torque[2][3];
+  double rk_rtol, rk_atol;
 };
 
 enum : uint32_t { FLAG_COLLIDED = 1u, FLAG_HALTED = 2u, SUCCESS_SHIFT = 2 };   // flags word: bit0, bit1, count << 2
@@ -172,6 +176,152 @@ __device__ __forceinline__ void integrate_attitude(double* q, const double* w, d
   const double o3 = fma(a, dz, fma(b, dy, fma(d, c, -cc * dx)));
   const double inv = rsqrt64(fma(o3, o3, fma(o2, o2, fma(o1, o1, o0 * o0))));   // :574, :601
   q[0] = o0 * inv; q[1] = o1 * inv; q[2] = o2 * inv; q[3] = o3 * inv;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// General rigid body (SURVEY f-4): any inertia tensor, constant body torque.  The reference integrates
+//   q' = 1/2 Omega(w) q/|q|,  w' = I^-1 (tau - w x I w)           (dynamics.py:93-175)
+// with scipy.integrate.solve_ivp(method='RK45', rtol=1e-7, atol=1e-6) over one dt (rendezvous_env.py:561-570, :588-597).
+// This is the same Dormand-Prince 5(4) pair with scipy's initial-step rule and step-size controller, operation for operation
+// (fused multiply-adds off in this section), in fp64: it takes the same accepted / rejected steps as scipy and lands within
+// rounding of its result.  Each lane runs its own adaptive loop (divergent trip counts; typically 1-3 steps per dt).
+__device__ __forceinline__ void rigid_rhs(const double* I, const double* Iinv, const double* tau, const double* y, double* dy) {
+#pragma clang fp contract(off)
+  const double mag = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);           // dynamics.py:109
+  const double a0 = y[0] / mag, a1 = y[1] / mag, a2 = y[2] / mag, a3 = y[3] / mag;
+  const double mag2 = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);                           // dynamics.py:134
+  const double q0 = a0 / mag2, q1 = a1 / mag2, q2 = a2 / mag2, q3 = a3 / mag2;
+  const double w1 = y[4], w2 = y[5], w3 = y[6];
+  dy[0] = 0.5 * (-w1 * q1 - w2 * q2 - w3 * q3);                                              // dynamics.py:137-151
+  dy[1] = 0.5 * (w1 * q0 + w3 * q2 - w2 * q3);
+  dy[2] = 0.5 * (w2 * q0 - w3 * q1 + w1 * q3);
+  dy[3] = 0.5 * (w3 * q0 + w2 * q1 - w1 * q2);
+  double L[3], r[3];                                                                         // dynamics.py:169-171
+#pragma unroll
+  for (int i = 0; i < 3; ++i) L[i] = I[3 * i] * w1 + I[3 * i + 1] * w2 + I[3 * i + 2] * w3;
+  r[0] = tau[0] - (w2 * L[2] - w3 * L[1]);
+  r[1] = tau[1] - (w3 * L[0] - w1 * L[2]);
+  r[2] = tau[2] - (w1 * L[1] - w2 * L[0]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dy[4 + i] = Iinv[3 * i] * r[0] + Iinv[3 * i + 1] * r[1] + Iinv[3 * i + 2] * r[2];
+}
+
+__device__ __forceinline__ double rms7(const double* x) {
+#pragma clang fp contract(off)
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) s += x[i] * x[i];
+  return sqrt(s) / sqrt(7.0);
+}
+
+constexpr int kRk45MaxAttempts = 4096;   // a lane that has not finished dt by then gets a NaN state (scipy would be failing too)
+
+__device__ __forceinline__ void integrate_attitude_rk45(double* q, double* w, const double* I, const double* Iinv, const double* tau,
+                                                        double t_bound, double rtol, double atol) {
+#pragma clang fp contract(off)
+  // Dormand-Prince coefficients (scipy/integrate/_ivp/rk.py RK45: A, B, E)
+  constexpr double A[6][5] = {{0, 0, 0, 0, 0},
+                              {1.0 / 5, 0, 0, 0, 0},
+                              {3.0 / 40, 9.0 / 40, 0, 0, 0},
+                              {44.0 / 45, -56.0 / 15, 32.0 / 9, 0, 0},
+                              {19372.0 / 6561, -25360.0 / 2187, 64448.0 / 6561, -212.0 / 729, 0},
+                              {9017.0 / 3168, -355.0 / 33, 46732.0 / 5247, 49.0 / 176, -5103.0 / 18656}};
+  constexpr double B[6] = {35.0 / 384, 0, 500.0 / 1113, 125.0 / 192, -2187.0 / 6784, 11.0 / 84};
+  constexpr double E[7] = {-71.0 / 57600, 0, 71.0 / 16695, -71.0 / 1920, 17253.0 / 339200, -22.0 / 525, 1.0 / 40};
+  double y[7] = {q[0], q[1], q[2], q[3], w[0], w[1], w[2]};
+  double f[7];
+  rigid_rhs(I, Iinv, tau, y, f);
+  double h_abs;
+  {  // select_initial_step (common.py), error order 4
+    double sa[7], sb[7], scale[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) { scale[i] = atol + fabs(y[i]) * rtol; sa[i] = y[i] / scale[i]; sb[i] = f[i] / scale[i]; }
+    const double d0 = rms7(sa), d1 = rms7(sb);
+    double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+    if (h0 > t_bound) h0 = t_bound;
+    double y1[7], f1[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) y1[i] = y[i] + h0 * f[i];
+    rigid_rhs(I, Iinv, tau, y1, f1);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) sa[i] = (f1[i] - f[i]) / scale[i];
+    const double d2 = rms7(sa) / h0;
+    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+    h_abs = fmin(fmin(100 * h0, h1), t_bound);
+  }
+  double t = 0.0;
+  int attempts = 0;
+  bool rejected = false;
+  bool failed = false;
+  double min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+  if (h_abs < min_step) h_abs = min_step;
+#pragma clang loop unroll(disable)
+  while (t < t_bound) {   // one ATTEMPT per trip (accepted or rejected); every lane leaves after at most kRk45MaxAttempts trips
+    double h = h_abs, t_new = t + h;
+    if (t_new - t_bound > 0) t_new = t_bound;
+    h = t_new - t;
+    h_abs = fabs(h);
+    double K[7][7], tmp[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) K[0][i] = f[i];
+#pragma unroll
+    for (int s = 1; s < 6; ++s) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) {
+        double dy = 0.0;
+#pragma unroll
+        for (int j = 0; j < s; ++j) dy += K[j][i] * A[s][j];
+        tmp[i] = y[i] + dy * h;
+      }
+      rigid_rhs(I, Iinv, tau, tmp, K[s]);
+    }
+    double y_new[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int s = 0; s < 6; ++s) acc += K[s][i] * B[s];
+      y_new[i] = y[i] + h * acc;
+    }
+    rigid_rhs(I, Iinv, tau, y_new, K[6]);
+    double err[7];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int s = 0; s < 7; ++s) acc += K[s][i] * E[s];
+      const double sc = atol + fmax(fabs(y[i]), fabs(y_new[i])) * rtol;
+      err[i] = acc * h / sc;
+    }
+    const double error_norm = rms7(err);
+    ++attempts;
+    if (error_norm < 1) {
+      double factor = error_norm == 0 ? 10.0 : fmin(10.0, 0.9 * pow(error_norm, -0.2));
+      if (rejected && factor > 1) factor = 1;
+      h_abs *= factor;
+      t = t_new;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) { y[i] = y_new[i]; f[i] = K[6][i]; }
+      rejected = false;
+      min_step = 10 * fabs(nextafter(t, INFINITY) - t);
+      if (h_abs < min_step) h_abs = min_step;
+    } else {
+      if (!(error_norm == error_norm) || h_abs <= min_step) { failed = true; break; }   // non-finite state / step size too small
+      h_abs *= fmax(0.2, 0.9 * pow(error_norm, -0.2));
+      if (h_abs < min_step) h_abs = min_step;
+      rejected = true;
+    }
+    if (attempts >= kRk45MaxAttempts) { failed = t < t_bound; break; }
+  }
+  if (failed) {
+#pragma unroll
+    for (int i = 0; i < 7; ++i) y[i] = __builtin_nan("");
+  }
+  const double mag = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);   // :574, :601
+#pragma unroll
+  for (int i = 0; i < 4; ++i) q[i] = y[i] / mag;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) w[i] = y[4 + i];
 }
 
 // Flags/reward inputs from the canonical state: one R(qc), one R(qt) per call (the reference rebuilds them ~10x per step).
@@ -421,7 +571,7 @@ struct StepResult {
 };
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
-template <typename ST, bool kLazy>
+template <typename ST, bool kLazy, bool kGeneral = false>
 __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d) {
   const ST tag = ST(0);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
@@ -443,8 +593,15 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   // :173, :180 delta_w = a[3:] * max_delta_w is a float64 product (max_delta_w is np.float64)
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = fma((double)a[3 + i], P.max_delta_w, e.wc[i]);
-  integrate_attitude(e.qc, e.wc, P.half_dt);   // :181
-  integrate_attitude(e.qt, e.wt, P.half_dt);   // :184
+  if (kGeneral) {   // general inertia / torque: the reference's own integrator (both rates evolve)
+    integrate_attitude_rk45(e.qc, e.wc, P.body_inertia[0], P.body_inv_inertia[0], P.body_torque[0], P.dt, P.rk_rtol, P.rk_atol);   // :181
+    integrate_attitude_rk45(e.qt, e.wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);   // :184
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e.wt[i] = canon(e.wt[i], tag);
+  } else {
+    integrate_attitude(e.qc, e.wc, P.half_dt);   // :181
+    integrate_attitude(e.qt, e.wt, P.half_dt);   // :184
+  }
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = canon(e.wc[i], tag);
 #pragma unroll

@@ -257,7 +257,7 @@ __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i,
 }
 
 // step one lane's env (or report a halted one); returns whether a transition was executed
-template <typename ST, bool kDiag>
+template <typename ST, bool kDiag, bool kGeneral = false>
 __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, int64_t i, bool active, Env& e, const float* a,
                                         StepResult& r) {
   r.done = 0; r.reason = 0; r.reward = 0.0f;
@@ -271,7 +271,7 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
       r.done = 1;
       if (kDiag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
     } else {
-      step_env<ST, !kDiag>(P, e, a, r, d);
+      step_env<ST, !kDiag, kGeneral>(P, e, a, r, d);
       stepped = true;
       if (kDiag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);   // evaluator build only: keeps the training kernel short
     }
@@ -282,7 +282,9 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
 // ---------------------------------------------------------------------------------------------------------------
 // Fused variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).
 // The right shape when the chip is full (several waves per SIMD): no work is done twice.
-template <typename ST, bool kDiag>
+// kGeneral: general rigid bodies (rdv_set_rigid_body) — the attitude of both bodies is integrated with the reference's RK45
+// scheme instead of the closed form, and the target's rate is part of the state that is written back.
+template <typename ST, bool kDiag, bool kGeneral = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   load_actions(A.actions, wave_base, rows, lane, active, wl, a);
 
   StepResult r;
-  const bool stepped = advance<ST, kDiag>(A, P, i, active, e, a, r);
+  const bool stepped = advance<ST, kDiag, kGeneral>(A, P, i, active, e, a, r);
   const bool fin = stepped && r.done;
   stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
   store_step_outputs<true>(A, i, active, fin, r, e);
@@ -337,8 +339,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
   wave_lds_fence();
   store_obs_rows(A.obs, wave_base, rows, lane, wl);
-  // state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt)
-  if (stepped) store_env<ST>(ws, n, i, e, did_reset);
+  // state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt, or always when wt evolves)
+  if (stepped) store_env<ST>(ws, n, i, e, did_reset || kGeneral);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -629,12 +631,15 @@ struct RdvEnvBatch {
   const double* tape;
   int32_t tape_depth;
   int variant;       // RdvKernelVariant
+  RdvRigidBody body; // rdv_set_rigid_body
+  bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
   std::vector<uint64_t> host_slots;
 };
 static constexpr uint32_t kMagic = 0x52445631u;   // "RDV1"
+static void apply_rigid_body(RdvEnvBatch* h);
 
 #define RDV_CHECK_HANDLE(h) \
   if (!(h) || (h)->magic != kMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_handle")
@@ -763,6 +768,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   RdvEnvBatch* h = new (std::nothrow) RdvEnvBatch();
   if (!h) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_create: host allocation failed");
   h->magic = kMagic; h->params = *params; derive_params(*params, h->dev);
+  (void)rdv_rigid_body_default(&h->body); h->general = false; apply_rigid_body(h);
   h->n = n_envs; h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
@@ -799,12 +805,93 @@ int rdv_destroy(rdv_handle h) {
   return RDV_OK;
 }
 
+// ---- rigid bodies (SURVEY f-4) -------------------------------------------------------------------------------------
+int rdv_rigid_body_default(RdvRigidBody* b) {
+  if (!b) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rigid_body_default: null output");
+  std::memset(b, 0, sizeof *b);
+  const double mass = 100.0, inertia = 1.0 * 1.0 / 12.0 * mass * 2.0;   // :74-79, :96-100
+  for (int i = 0; i < 3; ++i) { b->inertia_chaser[4 * i] = inertia; b->inertia_target[4 * i] = inertia; }
+  b->rtol = 1e-7; b->atol = 1e-6;                                        // :567-568
+  b->integrator = RDV_INTEGRATOR_AUTO;
+  return RDV_OK;
+}
+static bool invert3(const double* m, double* inv) {   // adjugate / determinant (np.linalg.inv at :80, :101 uses LU: same to rounding)
+  const double c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+  inv[0] = c00 / det; inv[1] = (m[2] * m[7] - m[1] * m[8]) / det; inv[2] = (m[1] * m[5] - m[2] * m[4]) / det;
+  inv[3] = c01 / det; inv[4] = (m[0] * m[8] - m[2] * m[6]) / det; inv[5] = (m[2] * m[3] - m[0] * m[5]) / det;
+  inv[6] = c02 / det; inv[7] = (m[1] * m[6] - m[0] * m[7]) / det; inv[8] = (m[0] * m[4] - m[1] * m[3]) / det;
+  return true;
+}
+static bool closed_form_applies(const double* inertia, const double* torque) {   // c * Identity, zero torque: w x (I w) = 0
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      if (i != j ? inertia[3 * i + j] != 0.0 : inertia[3 * i + j] != inertia[0]) return false;
+  return torque[0] == 0.0 && torque[1] == 0.0 && torque[2] == 0.0;
+}
+static int validate_rigid_body(const RdvRigidBody* b, bool* general) {
+  if (!b) return fail(RDV_ERR_INVALID_ARGUMENT, "null RdvRigidBody");
+  if (b->integrator != RDV_INTEGRATOR_AUTO && b->integrator != RDV_INTEGRATOR_EXACT && b->integrator != RDV_INTEGRATOR_RK45)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "RdvRigidBody: bad integrator %d", b->integrator);
+  const double* tensors[2] = {b->inertia_chaser, b->inertia_target};
+  const char* names[2] = {"inertia_chaser", "inertia_target"};
+  for (int k = 0; k < 2; ++k) {
+    const double* m = tensors[k];
+    for (int i = 0; i < 9; ++i) if (!std::isfinite(m[i])) return fail(RDV_ERR_BAD_PARAMS, "RdvRigidBody: %s is not finite", names[k]);
+    // a physical inertia tensor is symmetric positive definite (Sylvester's criterion)
+    const double tol = 1e-12 * (std::fabs(m[0]) + std::fabs(m[4]) + std::fabs(m[8]));
+    if (std::fabs(m[1] - m[3]) > tol || std::fabs(m[2] - m[6]) > tol || std::fabs(m[5] - m[7]) > tol)
+      return fail(RDV_ERR_BAD_PARAMS, "RdvRigidBody: %s is not symmetric", names[k]);
+    const double d2 = m[0] * m[4] - m[1] * m[3];
+    const double d3 = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (!(m[0] > 0.0 && d2 > 0.0 && d3 > 0.0)) return fail(RDV_ERR_BAD_PARAMS, "RdvRigidBody: %s is not positive definite", names[k]);
+  }
+  for (int i = 0; i < 3; ++i)
+    if (!std::isfinite(b->torque_chaser[i]) || !std::isfinite(b->torque_target[i])) return fail(RDV_ERR_BAD_PARAMS, "RdvRigidBody: torque is not finite");
+  if (!(b->rtol > 0.0 && std::isfinite(b->rtol) && b->atol > 0.0 && std::isfinite(b->atol)))
+    return fail(RDV_ERR_BAD_PARAMS, "RdvRigidBody: rtol and atol must be positive");
+  const bool closed = closed_form_applies(b->inertia_chaser, b->torque_chaser) && closed_form_applies(b->inertia_target, b->torque_target);
+  if (b->integrator == RDV_INTEGRATOR_EXACT && !closed)
+    return fail(RDV_ERR_BAD_PARAMS, "RdvRigidBody: the closed-form integrator needs inertia = c * Identity and zero torque for both bodies");
+  *general = b->integrator == RDV_INTEGRATOR_RK45 || !closed;
+  return RDV_OK;
+}
+static void apply_rigid_body(RdvEnvBatch* h) {   // h->body (validated) -> the kGeneral block of h->dev
+  const RdvRigidBody& b = h->body;
+  const double* tensors[2] = {b.inertia_chaser, b.inertia_target};
+  const double* torques[2] = {b.torque_chaser, b.torque_target};
+  for (int k = 0; k < 2; ++k) {
+    for (int i = 0; i < 9; ++i) h->dev.body_inertia[k][i] = tensors[k][i];
+    (void)invert3(tensors[k], h->dev.body_inv_inertia[k]);
+    for (int i = 0; i < 3; ++i) h->dev.body_torque[k][i] = torques[k][i];
+  }
+  h->dev.rk_rtol = b.rtol; h->dev.rk_atol = b.atol;
+}
+int rdv_set_rigid_body(rdv_handle h, const RdvRigidBody* b) {
+  RDV_CHECK_HANDLE(h);
+  bool general = false;
+  if (int rc = validate_rigid_body(b, &general)) return rc;
+  DeviceGuard guard(h->device);
+  h->body = *b; h->general = general;
+  apply_rigid_body(h);
+  RDV_HIP(hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice));
+  return RDV_OK;
+}
+int rdv_get_rigid_body(rdv_handle h, RdvRigidBody* out) {
+  RDV_CHECK_HANDLE(h);
+  if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_rigid_body: null output");
+  *out = h->body;
+  return RDV_OK;
+}
+
 int rdv_set_params(rdv_handle h, const RdvParams* p) {
   RDV_CHECK_HANDLE(h);
   if (int rc = rdv_params_validate(p)) return rc;
   DeviceGuard guard(h->device);
   h->params = *p; derive_params(*p, h->dev);
   h->dev.acos_table = h->acos_table;
+  apply_rigid_body(h);
   // blocking copy on the legacy default stream: ordered after work already enqueued on blocking streams
   RDV_HIP(hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice));
   return RDV_OK;
@@ -877,7 +964,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   A.stamps = h->stamps;
 #endif
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool split = h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs);
+  // general rigid bodies run on the fused layout only (their integrator is a per-lane adaptive loop: no fixed phase to split)
+  const bool split = !h->general && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
   const dim3 block(split ? kSplitBlock : kBlock);
   const dim3 grid = split ? dim3((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)) : grid_for(h->n);
 #define RDV_LAUNCH_STEP(KERNEL)                                                         \
@@ -891,7 +979,14 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
     }                                                                                   \
   } while (0)
   if (split) RDV_LAUNCH_STEP(step_kernel_split);
-  else RDV_LAUNCH_STEP(step_kernel);
+  else if (!h->general) RDV_LAUNCH_STEP(step_kernel);
+  else if (h->storage == RDV_STORAGE_F32) {
+    if (A.diag) hipLaunchKernelGGL((step_kernel<float, true, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+    else hipLaunchKernelGGL((step_kernel<float, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+  } else {
+    if (A.diag) hipLaunchKernelGGL((step_kernel<double, true, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+    else hipLaunchKernelGGL((step_kernel<double, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+  }
 #undef RDV_LAUNCH_STEP
   RDV_HIP(hipGetLastError());
   return RDV_OK;

@@ -178,6 +178,11 @@ class RendezvousVecEnv(_VecEnvBase):
                          att_coef=p.att_coef) for _ in idx]
         if attr_name in ("observation_space", "action_space", "quiet"):
             return [getattr(self, attr_name) for _ in idx]
+        if attr_name in ("inertia", "inv_inertia", "inertia_target", "inv_inertia_target"):   # :75-80, :96-101
+            body = self.batch.get_rigid_body()
+            m = body["inertia_target" if attr_name.endswith("target") else "inertia"]
+            m = np.linalg.inv(m) if attr_name.startswith("inv_") else m
+            return [m.copy() for _ in idx]
         raise AttributeError(f"RendezvousVecEnv has no per-env attribute '{attr_name}'")
 
     def set_attr(self, attr_name, value, indices=None):
@@ -190,6 +195,10 @@ class RendezvousVecEnv(_VecEnvBase):
             self.batch.set_params(p)
         elif attr_name == "quiet":
             self.quiet = bool(value)
+        elif attr_name == "inertia":                 # the inverse (:80, :101) follows the tensor
+            self.batch.set_rigid_body(inertia=value)
+        elif attr_name == "inertia_target":
+            self.batch.set_rigid_body(inertia_target=value)
         else:
             raise AttributeError(f"cannot set '{attr_name}' on RendezvousVecEnv")
 

@@ -61,6 +61,17 @@ def test_params_default_matches_reference_constructor():
     assert q.n == pytest.approx(1.039679077e-3, rel=1e-9)
 
 
+def test_rigid_body_default_matches_reference_constructor():
+    b = N.RigidBody()
+    assert C.sizeof(N.RigidBody) == 26 * 8 + 8            # include/rdv.h RdvRigidBody: 26 doubles + 2 int32
+    N.check(N.lib().rdv_rigid_body_default(C.byref(b)))
+    inertia = 1 / 12 * 100 * (2 * 1 ** 2)                 # rendezvous_env.py:75-79, :96-100
+    np.testing.assert_array_equal(np.array(b.inertia_chaser).reshape(3, 3), np.eye(3) * inertia)
+    np.testing.assert_array_equal(np.array(b.inertia_target).reshape(3, 3), np.eye(3) * inertia)
+    assert list(b.torque_chaser) == [0, 0, 0] and list(b.torque_target) == [0, 0, 0]      # :181, :184
+    assert (b.rtol, b.atol, b.integrator) == (1e-7, 1e-6, N.INTEGRATORS["auto"])           # :567-568
+
+
 def test_params_validate_reference_asserts():
     lib = N.lib()
     p = make_params()
