@@ -145,6 +145,85 @@ def run(policy, initial_states, device="cuda:0", storage="f32", config=None, det
     return out
 
 
+REPLICA_COLUMNS = ["ep_len", "num_collisions", "collided", "total_reward", "total_delta_v", "num_successes", "succeeded",
+                   "min_dist_from_koz"]
+
+
+@torch.no_grad()
+def evaluate_replicas(policy, env, states):
+    """Stochastic-action trajectories (SB3 ``predict(deterministic=False)``: mean + exp(log_std) N(0,1), clipped) from the given
+    initial states, one per env of the halting batch ``env``; all bookkeeping of monte_carlo.evaluate (:117-150) stays on the
+    device.  Returns the first 8 output columns (the terminal-error columns need the whole error history: see evaluate_batch)."""
+    p = env.params
+    states = np.array(states, dtype=np.float64, copy=True)
+    m = states.shape[0]
+    assert m == env.num_envs, (m, env.num_envs)
+    states[:, 6:10] /= np.linalg.norm(states[:, 6:10], axis=1, keepdims=True)        # :66
+    states[:, 13:17] /= np.linalg.norm(states[:, 13:17], axis=1, keepdims=True)      # :67
+    steps_max = int(p.t_max / p.dt) + 1                                              # :97
+    env.reset()                                                                      # :106
+    env.set_state(torch.from_numpy(states))
+    obs = env.observe()                                                              # :113
+    d0 = env.diagnose()
+    num_collisions, num_successes, min_dist = d0[:, 4].clone(), d0[:, 5].clone(), d0[:, 6].clone()   # :119-123
+    total_reward = torch.zeros_like(min_dist)
+    length = torch.zeros(m, dtype=torch.int64, device=min_dist.device)
+    active = torch.ones(m, dtype=torch.bool, device=min_dist.device)
+    for k in range(1, steps_max + 2):                                                # :126
+        actions = policy.act(obs, deterministic=False)                               # :128-133 with deterministic=False
+        obs, rew, done = env.step(actions.contiguous(), diag=True)                   # :136
+        dg = env.diag
+        num_collisions += torch.where(active, dg[:, 4], 0.0)                         # :142-144
+        num_successes += torch.where(active, dg[:, 5], 0.0)                          # :145-146
+        min_dist = torch.where(active, torch.minimum(min_dist, dg[:, 6]), min_dist)  # :147-149
+        total_reward += torch.where(active, rew.double(), 0.0)                       # :150
+        length = torch.where(active, k, length)
+        active &= ~done.bool()
+        if not bool(active.any()):
+            break
+    else:
+        raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
+    aux = env.get_aux()
+    cols = dict(ep_len=torch.round(length.double() * p.dt, decimals=3), num_collisions=num_collisions,
+                collided=(num_collisions > 0).double(), total_reward=total_reward, total_delta_v=aux[:, 4],
+                num_successes=num_successes, succeeded=(num_successes > 0).double(), min_dist_from_koz=min_dist)
+    return {c: cols[c].cpu().numpy() for c in REPLICA_COLUMNS}
+
+
+def run_replicas(policy, initial_states, replicas, device="cuda:0", storage="f32", config=None, seed=0, rank=0, world=1,
+                 engine_factory=None):
+    """BASELINE config 5: every initial condition x ``replicas`` exploration-noise seeds.  Trajectory g = replica * M + row is
+    global; ``rank`` of ``world`` evaluates its contiguous slice [lo, hi) of the M * replicas trajectories in ONE batch (no
+    collective on the data path) with the policy noise keyed by (seed, g, step), so results do not depend on the sharding.
+    Returns (columns of the local slice, (lo, hi))."""
+    from .sharding import shard_range
+    ics = np.asarray(initial_states, dtype=np.float64)
+    m = len(ics)
+    lo, hi = shard_range(m * int(replicas), rank, world)
+    params = make_eval_params(config)
+    if engine_factory is None:
+        from .batch import RendezvousBatch
+        env = RendezvousBatch(hi - lo, params=params, device=device, storage=storage, on_done="halt", seed=seed, env_id_offset=lo)
+        policy = policy.to(env.device)
+    else:
+        env = engine_factory(hi - lo, params)
+    policy.noise_seed, policy.noise_env_offset, policy._calls = int(seed), lo, 0
+    out = evaluate_replicas(policy, env, ics[np.arange(lo, hi) % m])
+    if hasattr(env, "close"):
+        env.close()
+    return out, (lo, hi)
+
+
+def replica_summary(columns, m):
+    """Success / collision percentage (:75-78) per replica and their mean and spread over the replicas."""
+    r = len(columns["succeeded"]) // m
+    succ = columns["succeeded"][: r * m].reshape(r, m).mean(axis=1) * 100
+    coll = columns["collided"][: r * m].reshape(r, m).mean(axis=1) * 100
+    return dict(replicas=r, trajectories=r * m, success_percent_mean=float(succ.mean()), success_percent_std=float(succ.std()),
+                collision_percent_mean=float(coll.mean()), collision_percent_std=float(coll.std()),
+                success_percent_min=float(succ.min()), success_percent_max=float(succ.max()))
+
+
 def summary(results):
     m = len(results["succeeded"])
     return dict(trajectories=m, success_percent=float(results["succeeded"].sum() / m * 100),     # :75-78
@@ -174,6 +253,9 @@ def main(argv=None):
     ap.add_argument("--storage", choices=["f32", "f64"], default="f32")
     ap.add_argument("--stochastic", action="store_true", help="sample actions (mean + std*N) instead of the mean")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--replicas", type=int, default=0,
+                    help="additionally run this many exploration-noise replicas of every initial condition (sharded over the "
+                         "ranks when launched with torchrun)")
     args = ap.parse_args(argv)
     from .policy import MlpPolicy
     policy = MlpPolicy.from_npz(args.model) if args.model.endswith(".npz") else MlpPolicy.from_sb3_zip(args.model)
@@ -188,7 +270,35 @@ def main(argv=None):
     print(f"Collision%: {s['collision_percent']}")
     if args.save:
         print(f"Saving results to '{save_csv(res)}'... Done")
+    if args.replicas > 0:
+        res["replicas"] = main_replicas(policy, ics, args)
     return res
+
+
+def main_replicas(policy, ics, args):
+    """--replicas R: one process per GPU under torchrun (RANK / WORLD_SIZE / LOCAL_RANK), or a single process."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    device = args.device
+    if world > 1:
+        gpu = torch.cuda.is_available()
+        if gpu:
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+            torch.cuda.set_device(device)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl" if gpu else "gloo")
+    cols, _ = run_replicas(policy, ics, args.replicas, device=device, storage=args.storage, seed=args.seed, rank=rank, world=world)
+    if world > 1:
+        from .sharding import gather_columns
+        cols = gather_columns(cols, dst=0)
+    if cols is None:
+        return None
+    s = replica_summary(cols, len(ics))
+    print(f"{s['replicas']} stochastic replicas x {len(ics)} initial conditions = {s['trajectories']} trajectories")
+    print(f"Success %: {s['success_percent_mean']:.3f} +- {s['success_percent_std']:.3f} over replicas "
+          f"[{s['success_percent_min']:.1f}, {s['success_percent_max']:.1f}]")
+    print(f"Collision%: {s['collision_percent_mean']:.3f} +- {s['collision_percent_std']:.3f}")
+    return s
 
 
 if __name__ == "__main__":

@@ -22,6 +22,7 @@ class MlpPolicy(torch.nn.Module):
         super().__init__()
         self.backend = backend          # "auto": HIP kernel for CUDA observations, PyTorch otherwise; "torch"; "hip"
         self.noise_seed = int(seed)     # HIP backend: Philox key of the exploration noise; the call counter is the step index
+        self.noise_env_offset = 0       # HIP backend: global index of row 0 (sharded batches: noise keyed by global env id)
         self._hip = {}                  # device index -> rdv_policy handle
         self._calls = 0
         self.l1 = torch.nn.Linear(obs_dim, hidden)
@@ -80,7 +81,7 @@ class MlpPolicy(torch.nn.Module):
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
         N.check(N.lib().rdv_policy_act(self._hip_handle(obs.device), C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()), n,
                                        int(bool(deterministic)), C.c_uint64(self.noise_seed), C.c_uint64(self._calls),
-                                       C.c_uint64(0), stream))
+                                       C.c_uint64(self.noise_env_offset), stream))
         self._calls += 1
         return out
 

@@ -312,3 +312,26 @@ def test_record_trajectories_layout_and_consistency(tmp_path):
     with open(path, "rb") as f:
         back = pickle.load(f)                          # our own file
     np.testing.assert_array_equal(back["qt"], recs[0]["qt"])
+
+
+def test_monte_carlo_replicas_bookkeeping_on_the_oracle_engine():
+    """BASELINE config 5 host logic: stochastic replicas of the stored initial conditions, sharded by global trajectory index.
+    (The deterministic table is pinned elsewhere; here: the device-side bookkeeping equals evaluate_batch's host-side one when
+    both see the same actions, and the shards tile the replica space.)"""
+    ics = load_golden("mc_initial_conditions.npz")["states"][:96]
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    pol.log_std.data.fill_(-30.0)                       # exp(-30) * N(0,1): below float32 resolution of the actions -> the mean
+    factory = lambda n, params: OracleEngine(n, params, storage="f64", on_done="halt")
+    det = mc.run(pol, ics, engine_factory=factory)
+    parts, spans = [], []
+    for rank in range(3):
+        cols, span = mc.run_replicas(pol, ics, replicas=2, rank=rank, world=3, engine_factory=factory)
+        parts.append(cols); spans.append(span)
+    assert spans == [(0, 64), (64, 128), (128, 192)]
+    full = {c: np.concatenate([p[c] for p in parts]) for c in mc.REPLICA_COLUMNS}
+    for c in mc.REPLICA_COLUMNS:                        # replica r of row i = trajectory r*M + i
+        np.testing.assert_allclose(full[c][:96], det[c], rtol=0, atol=1e-9, err_msg=c)
+        np.testing.assert_allclose(full[c][96:], det[c], rtol=0, atol=1e-9, err_msg=c)
+    s = mc.replica_summary(full, 96)
+    assert s["replicas"] == 2 and s["trajectories"] == 192 and s["success_percent_std"] == 0.0
+    assert s["success_percent_mean"] == pytest.approx(mc.summary(det)["success_percent"])
