@@ -265,6 +265,23 @@ def main():
                 out["policy_rollout"][key] = rollout_rate(backend, graph)
             except Exception as exc:  # pragma: no cover - depends on the runtime
                 out["policy_rollout"][key + "_error"] = repr(exc)
+        try:   # the whole closed loop as ONE persistent launch per 64 steps (rdv_rollout): state in registers, obs/actions in LDS
+            pol.backend = "hip"
+            env.reset()
+            t_roll = 64
+            bufs = env.rollout(pol, t_roll)
+            for _ in range(2):
+                env.rollout(pol, t_roll, out=bufs)
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            for _ in range(k2 // t_roll * 4):
+                env.rollout(pol, t_roll, out=bufs)
+            torch.cuda.synchronize()
+            out["policy_rollout"]["hip_rollout_kernel"] = n * (k2 // t_roll * 4) * t_roll / (time.perf_counter() - p0)
+            out["policy_rollout"]["hip_rollout_kernel_steps_per_launch"] = t_roll
+            del bufs
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            out["policy_rollout"]["hip_rollout_kernel_error"] = repr(exc)
         out["policy_rollout"]["value"] = max(v for k_, v in out["policy_rollout"].items() if isinstance(v, float))
         pol.close()
         # the SB3-facing NumPy boundary (actions H2D, obs/reward/done D2H, infos) — PCIe-inclusive, never the bench value

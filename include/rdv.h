@@ -243,6 +243,24 @@ int rdv_policy_destroy(rdv_policy p);
 int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, int deterministic, uint64_t seed,
                    uint64_t counter, uint64_t env_id_offset, void* stream);
 
+/*
+ * Closed-loop rollout collection in ONE launch: for t in [0, n_steps): a_t ~ actor(obs_t); obs_{t+1}, r_t, done_t =
+ * step(clip(a_t)) — the inner loop of SB3's OnPolicyAlgorithm.collect_rollouts (what model.learn, main.py:114, spends its
+ * env time in) with the actor above, writing the rows SB3's RolloutBuffer.add receives.  Results are those of
+ * rdv_policy_act(counter = noise_counter0 + t, env_id_offset = the handle's) followed by rdv_step, n_steps times; the env
+ * state stays in registers and the observations / actions in LDS in between.  Episode statistics accumulate as in rdv_step.
+ */
+typedef struct RdvRolloutOut {
+  float*   obs;        /* [T,N,17] required: the observation the actor saw at step t (buffer.observations) */
+  float*   actions;    /* [T,N,6]  required: the sampled action BEFORE clipping (buffer.actions); the env is stepped with clip(a, -1, 1) */
+  float*   reward;     /* [T,N]    required */
+  uint8_t* done;       /* [T,N]    required (buffer.episode_starts of step t+1) */
+  float*   log_prob;   /* [T,N]    nullable: log-density of actions[t] under the actor's diagonal Gaussian (buffer.log_probs) */
+  float*   last_obs;   /* [N,17]   required: the observation after the last step (SB3 _last_obs), reset observations included */
+} RdvRolloutOut;
+int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut* out_host, int deterministic,
+                uint64_t noise_seed, uint64_t noise_counter0, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -26,7 +26,7 @@ SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_va
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
            "rdv_set_kernel_variant", "rdv_rigid_body_default", "rdv_set_rigid_body", "rdv_get_rigid_body",
            "rdv_reset", "rdv_step", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_observe", "rdv_diagnose",
-           "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act"]
+           "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act", "rdv_rollout"]
 
 
 class RdvError(RuntimeError):
@@ -53,6 +53,12 @@ class Stats(C.Structure):
                     collisions=int(self.collisions), reasons=[int(x) for x in self.reasons],
                     sum_return=float(self.sum_return), sum_length=float(self.sum_length),
                     sum_delta_v=float(self.sum_delta_v), sum_delta_w=float(self.sum_delta_w))
+
+
+class RolloutOut(C.Structure):
+    """RdvRolloutOut: device pointers of the rollout-buffer rows"""
+    _fields_ = [("obs", C.c_void_p), ("actions", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p),
+                ("log_prob", C.c_void_p), ("last_obs", C.c_void_p)]
 
 
 INTEGRATORS = {"auto": 0, "exact": 1, "rk45": 2}
@@ -119,6 +125,7 @@ def lib():
         "rdv_policy_create": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]),
         "rdv_policy_destroy": (C.c_int, [vp]),
         "rdv_policy_act": (C.c_int, [vp, vp, vp, i64, C.c_int, u64, u64, u64, vp]),
+        "rdv_rollout": (C.c_int, [vp, vp, i32, C.POINTER(RolloutOut), C.c_int, u64, u64, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)

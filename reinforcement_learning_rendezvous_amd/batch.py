@@ -115,6 +115,29 @@ class RendezvousBatch:
         N.check(self._lib.rdv_step(self._h, actions.data_ptr(), C.byref(out), self._stream()))
         return self.obs, self.reward, self.done
 
+    def rollout(self, policy, n_steps, deterministic=False, out=None):
+        """``n_steps`` of the closed loop  a_t ~ policy(obs_t); obs_{t+1}, r_t, done_t = step(clip(a_t))  in ONE kernel launch
+        (the inner loop of SB3's ``collect_rollouts``, main.py:114): the env state stays in registers, observations and
+        actions in LDS.  Same results as ``policy.act`` + ``step`` called ``n_steps`` times.
+
+        Returns a dict of tensors shaped like SB3's RolloutBuffer rows: ``obs`` [T,N,17] (what the actor saw), ``actions``
+        [T,N,6] (before clipping), ``reward`` [T,N], ``done`` [T,N] (uint8), ``log_prob`` [T,N], ``last_obs`` [N,17]; pass
+        the dict back as ``out`` to reuse the buffers.  ``policy`` is an MlpPolicy (its HIP handle and noise key are used)."""
+        T, n, dev = int(n_steps), self.num_envs, self.device
+        if out is None or out["obs"].shape[0] != T:
+            out = dict(obs=torch.empty((T, n, N.OBS_DIM), dtype=torch.float32, device=dev),
+                       actions=torch.empty((T, n, N.ACT_DIM), dtype=torch.float32, device=dev),
+                       reward=torch.empty((T, n), dtype=torch.float32, device=dev),
+                       done=torch.empty((T, n), dtype=torch.uint8, device=dev),
+                       log_prob=torch.empty((T, n), dtype=torch.float32, device=dev),
+                       last_obs=torch.empty((n, N.OBS_DIM), dtype=torch.float32, device=dev))
+        ro = N.RolloutOut(*[out[f].data_ptr() for f, _ in N.RolloutOut._fields_])
+        N.check(self._lib.rdv_rollout(self._h, policy._hip_handle(dev), T, C.byref(ro), int(bool(deterministic)),
+                                      C.c_uint64(policy.noise_seed), C.c_uint64(policy._calls), self._stream()))
+        policy._calls += T
+        self.obs.copy_(out["last_obs"])      # the batch's current observation, as after step()
+        return out
+
     # ------------------------------------------------------------------------------------------------ evaluator helpers
     def set_state(self, states):
         """Overwrite rc, vc, qc, wc, qt, wt ([N,20] float64, CSV column order) as monte_carlo.py:107-112 does."""

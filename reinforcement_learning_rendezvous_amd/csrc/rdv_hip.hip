@@ -513,6 +513,10 @@ __global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void*
   }
 }
 
+}  // namespace rdv
+#include "rdv_rollout.h"
+namespace rdv {
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 static thread_local char g_err[512] = "";
@@ -632,6 +636,7 @@ struct RdvEnvBatch {
   int32_t tape_depth;
   int variant;       // RdvKernelVariant
   RdvRigidBody body; // rdv_set_rigid_body
+  bool rollout_ready;   // the rollout kernel's dynamic-LDS limit has been raised on this device
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
@@ -752,6 +757,37 @@ int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, in
   return RDV_OK;
 }
 
+int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut* out, int deterministic, uint64_t noise_seed,
+                uint64_t noise_counter0, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!p || p->magic != kPolicyMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_policy");
+  if (p->device != h->device) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: the policy lives on device %d, the envs on device %d", p->device, h->device);
+  if (n_steps <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: n_steps must be positive (got %d)", n_steps);
+  if (!out || !out->obs || !out->actions || !out->reward || !out->done || !out->last_obs)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: obs, actions, reward, done and last_obs are required");
+  if ((reinterpret_cast<uintptr_t>(out->obs) & 15) || (reinterpret_cast<uintptr_t>(out->actions) & 15) || (reinterpret_cast<uintptr_t>(out->last_obs) & 15))
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: obs, actions and last_obs must be 16-byte aligned");
+  if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: call rdv_reset first (state is undefined until reset(), as in the reference)");
+  if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_policy_act + rdv_step");
+  DeviceGuard guard(h->device);
+  if (!h->rollout_ready) {   // 117 KiB of dynamic LDS (above the 64 KiB default limit)
+    RDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes));
+    RDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes));
+    h->rollout_ready = true;
+  }
+  RolloutArgs A;
+  A.ws = h->ws; A.stats = h->stats; A.obs = out->obs; A.actions = out->actions; A.reward = out->reward; A.done = out->done;
+  A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.seed = h->seed;
+  A.env_id_offset = h->env_id_offset; A.noise_seed = noise_seed; A.noise_counter0 = noise_counter0;
+  A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps; A.deterministic = deterministic ? 1 : 0;
+  const dim3 grid((unsigned)((h->n + kRollEnvs - 1) / kRollEnvs)), block(kRollBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(rollout_kernel<float>, grid, block, kRollLdsBytes, s, h->dev_params, p->weights, A);
+  else hipLaunchKernelGGL(rollout_kernel<double>, grid, block, kRollLdsBytes, s, h->dev_params, p->weights, A);
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
+}
+
 int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage, int on_done, uint64_t seed,
                uint64_t env_id_offset, void* workspace, rdv_handle* out) {
   if (!params || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: null params/out");
@@ -769,6 +805,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   if (!h) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_create: host allocation failed");
   h->magic = kMagic; h->params = *params; derive_params(*params, h->dev);
   (void)rdv_rigid_body_default(&h->body); h->general = false; apply_rigid_body(h);
+  h->rollout_ready = false;
   h->n = n_envs; h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);

@@ -7,8 +7,10 @@
 // fp32, because bf16 would move the actions in the third decimal, i.e. change the trajectories:
 //   - a 512-thread workgroup owns 256 envs; each of its 8 waves computes the three layers for 32 envs as
 //     [32 envs x K] . [K x 64] with v_mfma_f32_32x32x2_f32 (exact fp32, accumulation in k order).  Eight waves put two on
-//     every SIMD: while one runs its MFMAs (the matrix pipe is per SIMD), the other does its bias + tanh on the vector
-//     pipe and its LDS traffic — a single 64-env wave per SIMD serialised the two (18-20 us per call);
+//     every SIMD, which hides one wave's LDS round trips and barrier-free hand-overs behind the other (a single 64-env wave per
+//     SIMD: 18-20 us per call).  Measured: the fp32-input MFMA runs at the fp32 VECTOR rate and its time ADDS to the vector work
+//     of the SIMD's waves (kernel = 6.9 us without the MFMAs + 5.3 us with them; static priorities or shifting the two waves against
+//     each other change nothing) — the matrix time of this kernel is a floor of 5.1 us at 65,536 envs, not something to hide;
 //   - the weights (30 KB, k-major) are copied to LDS once per workgroup; a B fragment is then one conflict-free
 //     ds_read_b32 per lane (lane l: W[2p + l/32][n0 + l%32]).  Fetching them from global memory inside the k loop, or
 //     through scalar loads into VALU FMAs (the first version), left a lone wave waiting on a cache round trip per k-pair;
@@ -85,13 +87,26 @@ __device__ __forceinline__ void dense_layer(const float* in, const float* Wt, in
 #pragma unroll
     for (int e = 0; e < 16; ++e) d[nt][e] = bc;
   }
-#pragma unroll
-  for (int p = 0; p < KPAD / 2; ++p) {
-    const int k = 2 * p + kk;                               // A: lane l holds in[row l%32][2p + l/32]; B: Wt[2p + l/32][col l%32]
+  // operands are read kDepth k-pairs ahead of the MFMAs that use them: read -> wait -> MFMA in lockstep leaves the matrix pipe idle
+  // for an LDS round trip per k-pair (the compiler does not hoist the reads by itself)
+  constexpr int P = KPAD / 2, kDepth = 4;
+  float av[P], bv[P][NT];
+  auto fetch = [&](int p) {
+    const int k = 2 * p + kk;                                 // A: lane l holds in[row l%32][2p + l/32]; B: Wt[2p + l/32][col l%32]
     const bool kin = (KPAD == K) || (k < K);
-    const float a = kin ? in[r * LD + k] : 0.0f;
+    av[p] = kin ? in[r * LD + k] : 0.0f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Wt[k * wld + nt * 32 + r], d[nt], 0, 0, 0);
+    for (int nt = 0; nt < NT; ++nt) bv[p][nt] = Wt[k * wld + nt * 32 + r];
+  };
+#pragma unroll
+  for (int p = 0; p < kDepth && p < P; ++p) fetch(p);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (p + kDepth < P) fetch(p + kDepth);
+    __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead: the scheduler otherwise sinks each one next to its MFMA
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][nt], d[nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   }
   wave_fence();
 #pragma unroll

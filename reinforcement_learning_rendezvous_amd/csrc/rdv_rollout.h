@@ -1,0 +1,256 @@
+// rdv_rollout.h — closed-loop rollout collection as ONE persistent launch: for t in 0..T-1
+//     a_t ~ actor(obs_t)  (SB3 MlpPolicy, mean + exp(log_std) N(0,1));  obs_{t+1}, r_t, done_t = env.step(clip(a_t))
+// i.e. the inner loop of SB3's OnPolicyAlgorithm.collect_rollouts (the caller of the env on the reference's training path,
+// main.py:114 -> model.learn) for the shipped actor, writing the rows of its rollout buffer (observations, actions before
+// clipping, rewards, dones, log-probabilities) and the observation after the last step.
+//
+// Included by rdv_hip.hip after the step helpers.  Same arithmetic as rdv_policy_act + rdv_step called T times (the tests
+// require bit-identical observations, rewards, dones and final state); what changes is where the data lives between steps:
+//   - one 768-thread workgroup owns 256 envs for the whole rollout.  Waves 0-3 ("env waves", 64 envs each, one lane per env)
+//     keep the env state in registers from the first step to the last; waves 4-11 ("actor waves", 32 envs each) keep the
+//     weights in LDS.  A workgroup puts one env wave and two actor waves on every SIMD;
+//   - the current observations [256,17] and actions [256,6] are handed over through LDS; two workgroup barriers per step;
+//   - nothing is re-read from HBM between steps and there is no launch boundary: of the 19 us a policy_act + step pair takes
+//     at 65,536 envs, ~5 us are launch gaps and kernel entry/exit, and the state / observation round trips.
+// Phase A (actor waves): obs_t rows -> HBM; 17->64->64 on v_mfma_f32_32x32x2_f32 (rdv_policy.h), head, noise, clip -> LDS and HBM.
+// Phase B (env waves): transition, reward/done -> HBM, in-lane reset where an episode ended, obs_{t+1} -> LDS.
+// (Measured and dropped: preparing every env's next initial state in LDS while the env waves wait for the actor — the fp64 filler
+// work slows the actor waves of the same SIMD by as much as the in-lane reset costs; and drawing the noise before the layers in
+// every second actor wave, or a static priority for one of them, to shift the two actor waves of a SIMD against each other — no
+// effect: the fp32-input MFMA time adds to the vector work, rdv_policy.h.)
+#pragma once
+
+namespace rdv {
+
+constexpr int kRollEnvs = 256;                       // envs per workgroup
+constexpr int kRollEnvWaves = kRollEnvs / kWave;     // 4
+constexpr int kRollActorWaves = kRollEnvs / kPolWaveEnvs;   // 8
+constexpr int kRollBlock = (kRollEnvWaves + kRollActorWaves) * kWave;   // 768 threads
+// dynamic LDS: weights | 8 actor images | current observations [256][17] | current (clipped) actions [256][6] | 4 statistics slots
+constexpr int kRollLdsFloats = kPolFloats + kRollActorWaves * kPolImgFloats + kRollEnvs * RDV_OBS_DIM + kRollEnvs * RDV_ACT_DIM +
+                               kRollEnvWaves * kStatWords * 2;
+constexpr int kRollLdsBytes = kRollLdsFloats * 4;    // 120,480 B: one workgroup per CU
+
+
+struct RolloutArgs {
+  void* ws;                 // chunk arrays (state in, state out)
+  uint64_t* stats;          // [n_waves][16]
+  float* obs;               // [T][N][17]  observation the actor saw at step t (SB3 buffer.observations)
+  float* actions;           // [T][N][6]   sampled action BEFORE clipping (SB3 buffer.actions); the env gets the clipped one
+  float* reward;            // [T][N]
+  uint8_t* done;            // [T][N]
+  float* log_prob;          // nullable [T][N]  log N(a_t; mean, exp(log_std)) summed over the 6 components
+  float* last_obs;          // [N][17]  observation after the last step (SB3 _last_obs)
+  const double* tape;       // nullable [depth][N][20]
+  int64_t n;
+  uint64_t seed;            // reset RNG (as rdv_step)
+  uint64_t env_id_offset;
+  uint64_t noise_seed;      // exploration noise: Philox key; counter = noise_counter0 + t (as rdv_policy_act)
+  uint64_t noise_counter0;
+  int32_t tape_depth;
+  int32_t on_done;
+  int32_t n_steps;
+  int32_t deterministic;
+};
+
+template <typename ST>
+__global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __restrict__ Pp, const float* __restrict__ W,
+                                                             const RolloutArgs A) {
+  using V = typename Vec4<ST>::type;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* w = lds;
+  float* images = w + kPolFloats;
+  float* obs_cur = images + kRollActorWaves * kPolImgFloats;
+  float* act_cur = obs_cur + kRollEnvs * RDV_OBS_DIM;
+  uint64_t* stat_lds = reinterpret_cast<uint64_t*>(act_cur + kRollEnvs * RDV_ACT_DIM);   // [4][16]: the rollout's statistics per env wave
+  const DevParams& P = *Pp;   // scalar loads (see step_kernel)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x >> 6;
+  const bool env_role = wv < kRollEnvWaves;
+  const int64_t n = A.n;
+  const int64_t block_base = (int64_t)blockIdx.x * kRollEnvs;
+  const int T = A.n_steps;
+
+  // ---- weights -> LDS, once per rollout
+  for (int q = threadIdx.x; q < kPolFloats / 4; q += kRollBlock)
+    *reinterpret_cast<float4*>(w + 4 * q) = *reinterpret_cast<const float4*>(W + 4 * q);
+
+  // ---- env waves: state -> registers, first observation -> LDS
+  const int slot = (wv & (kRollEnvWaves - 1)) * kWave + lane;     // env waves: the env of this lane
+  const int64_t i = block_base + slot;
+  const int64_t wave_base = i - lane;
+  const bool active = env_role && i < n;
+  const int64_t env_rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  Env e;
+  bool wt_dirty = false;
+  uint64_t* my_stats = stat_lds + (wv & (kRollEnvWaves - 1)) * kStatWords;
+  if (env_role) {
+    if (lane < kStatWords) my_stats[lane] = 0ull;
+    __builtin_amdgcn_s_setprio(2);   // the env wave is the one fp64 dependency chain of its SIMD
+    float o[RDV_OBS_DIM];
+#pragma unroll
+    for (int j = 0; j < RDV_OBS_DIM; ++j) o[j] = 0.0f;
+    if (active) {
+      load_env<ST>(reinterpret_cast<const V*>(A.ws), n, i, e);
+      observation(P, e, o);
+    }
+#pragma unroll
+    for (int j = 0; j < RDV_OBS_DIM; ++j) obs_cur[slot * RDV_OBS_DIM + j] = o[j];
+  }
+  __syncthreads();
+
+  // actor waves: rows [32a, 32a + 32) of the workgroup
+  const int a_wave = wv - kRollEnvWaves;
+  const int r0 = a_wave * kPolWaveEnvs;
+  const int64_t a_env0 = block_base + r0;
+  const int64_t a_rows = env_role ? 0 : ((n - a_env0) < kPolWaveEnvs ? (n - a_env0) : kPolWaveEnvs);
+  float* img = images + (env_role ? 0 : a_wave) * kPolImgFloats;
+  const bool vec_rows = (n & 3) == 0;   // [t][n][17] rows of a wave start 16-byte aligned
+
+  StepArgs SA;   // advance() only reads the diagnostics pointer (not used here)
+  SA.diag = nullptr;
+
+  // Two role-specific loops (so that neither role's registers are live in the other's code); every wave executes exactly
+  // two workgroup barriers per step.
+  if (!env_role) {
+   for (int t = 0; t < T; ++t) {
+    if (a_rows > 0) {
+      // ------------------------------------------------------------------ phase A: actor
+      const float* xin = obs_cur + r0 * RDV_OBS_DIM;
+      {  // obs_t rows -> HBM (what the actor is about to see)
+        float* dst = A.obs + ((int64_t)t * n + a_env0) * RDV_OBS_DIM;
+        if (a_rows == kPolWaveEnvs && vec_rows) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const int q = k * 64 + lane;
+            if (q < kPolWaveEnvs * RDV_OBS_DIM / 4) *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(xin + 4 * q);
+          }
+        } else {
+          const int64_t valid = a_rows * RDV_OBS_DIM;
+          for (int j = 0; j < 9; ++j) {
+            const int idx = j * 64 + lane;
+            if (idx < valid) dst[idx] = xin[idx];
+          }
+        }
+      }
+      const int er = lane & 31;
+      dense_layer<kPolIn, kPolInPad, kPolIn, 2, true>(xin, w + kPolW1, kPolHid, w + kPolB1, img, lane);     // 17 -> 64, tanh
+      dense_layer<kPolHid, kPolHid, kPolImgLd, 2, true>(img, w + kPolW2, kPolHid, w + kPolB2, img, lane);   // 64 -> 64, tanh
+      float out[kPolOut];
+      {  // 64 -> 6 on the vector pipe (rdv_policy.h)
+        const int k0 = (lane >> 5) * (kPolHid / 2);
+        const float* h = img + er * kPolImgLd + k0;
+        const float* w3 = w + kPolW3 + k0 * kPolOutPad;
+#pragma unroll
+        for (int j = 0; j < kPolOut; ++j) out[j] = 0.0f;
+#pragma unroll
+        for (int q = 0; q < kPolHid / 2; ++q) {
+          const float a = h[q];
+          const float4 wa = *reinterpret_cast<const float4*>(w3 + q * kPolOutPad);
+          const float2 wb = *reinterpret_cast<const float2*>(w3 + q * kPolOutPad + 4);
+          out[0] = fmaf(a, wa.x, out[0]); out[1] = fmaf(a, wa.y, out[1]); out[2] = fmaf(a, wa.z, out[2]);
+          out[3] = fmaf(a, wa.w, out[3]); out[4] = fmaf(a, wb.x, out[4]); out[5] = fmaf(a, wb.y, out[5]);
+        }
+#pragma unroll
+        for (int j = 0; j < kPolOut; ++j) out[j] = (out[j] + __shfl_xor(out[j], 32)) + w[kPolB3 + j];
+      }
+      float logp = -5.5136312f;   // -6/2 * log(2 pi)
+      if (!A.deterministic) {
+        const uint64_t id = A.env_id_offset + (uint64_t)(a_env0 + er);
+        const uint64_t counter = A.noise_counter0 + (uint64_t)t;
+        float z[8];
+#pragma unroll
+        for (uint32_t b = 0; b < 2; ++b) {
+          uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32), c2 = (uint32_t)counter, c3 = (uint32_t)(counter >> 32) * 2u + b;
+          philox4x32_10(c0, c1, c2, c3, (uint32_t)A.noise_seed, (uint32_t)(A.noise_seed >> 32) ^ 0x504F4C49u);
+          box_muller(c0, c1, z[4 * b + 0], z[4 * b + 1]);
+          box_muller(c2, c3, z[4 * b + 2], z[4 * b + 3]);
+        }
+#pragma unroll
+        for (int j = 0; j < kPolOut; ++j) {
+          out[j] = fmaf(w[kPolStd + j], z[j], out[j]);
+          logp = fmaf(-0.5f * z[j], z[j], logp);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kPolOut; ++j) logp -= __logf(w[kPolStd + j]);
+      // raw actions -> the wave's image (staging) -> HBM; clipped actions -> LDS for the env waves
+      wave_fence();   // every lane is done with the image
+      if (lane < kPolWaveEnvs) {
+#pragma unroll
+        for (int j = 0; j < kPolOut; ++j) {
+          img[lane * kPolOut + j] = out[j];
+          const float c = (out[j] != out[j]) ? out[j] : fminf(fmaxf(out[j], -1.0f), 1.0f);   // np.clip (NaN stays NaN)
+          act_cur[(r0 + lane) * RDV_ACT_DIM + j] = c;
+        }
+        if (A.log_prob && lane < a_rows) A.log_prob[(int64_t)t * n + a_env0 + lane] = logp;
+      }
+      wave_fence();
+      {
+        float* dst = A.actions + ((int64_t)t * n + a_env0) * RDV_ACT_DIM;
+        const int64_t valid = a_rows * RDV_ACT_DIM;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int idx = k * 128 + lane * 2;
+          if (idx + 1 < valid) {
+            *reinterpret_cast<float2*>(dst + idx) = *reinterpret_cast<const float2*>(img + idx);
+          } else if (idx < valid) {
+            dst[idx] = img[idx];
+          }
+        }
+      }
+    }
+    __syncthreads();   // actions of step t are in LDS
+    __syncthreads();   // observations of step t+1 are in LDS
+   }
+  } else {
+   const bool resets = A.on_done == RDV_ON_DONE_RESET;
+   for (int t = 0; t < T; ++t) {
+    __syncthreads();   // actions of step t are in LDS
+    {
+      // ------------------------------------------------------------------ phase B: env transition
+      float a[RDV_ACT_DIM];
+#pragma unroll
+      for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[slot * RDV_ACT_DIM + j] : 0.0f;
+      StepResult r;
+      const bool stepped = advance<ST, false>(SA, P, i, active, e, a, r);
+      const bool fin = stepped && r.done;
+      if (active) {
+        A.reward[(int64_t)t * n + i] = r.reward;
+        A.done[(int64_t)t * n + i] = (uint8_t)r.done;
+      }
+      // episode statistics: the same wavefront reduction as rdv_step (same order of the fp64 sums), into the wave's LDS slot
+      stats_update(my_stats, lane < 12 ? my_stats[lane] : 0ull, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+      if (fin) {
+        if (resets) {
+          const double* row = nullptr;
+          if (A.tape_depth > 0) row = A.tape + ((int64_t)(e.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
+          reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, row);
+          observation(P, e, r.obs);
+          wt_dirty = true;
+        } else {
+          e.flags |= FLAG_HALTED;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < RDV_OBS_DIM; ++j) obs_cur[slot * RDV_OBS_DIM + j] = r.obs[j];
+    }
+    __syncthreads();   // observations of step t+1 are in LDS
+   }
+  }
+
+  if (env_role) {
+    // ---- the observation after the last step, the state and the statistics go back to HBM
+    store_obs_rows(A.last_obs, wave_base, env_rows, lane, obs_cur + (slot - lane) * RDV_OBS_DIM);
+    if (active) store_env<ST>(reinterpret_cast<V*>(A.ws), n, i, e, wt_dirty);
+    if (env_rows > 0 && lane < 12) {   // this wave's statistics slot in HBM += the rollout's (counters as integers, sums as fp64)
+      uint64_t* slot_stats = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
+      const uint64_t pre = slot_stats[lane], add = my_stats[lane];
+      const uint64_t as_int = pre + add;
+      const uint64_t as_real = (uint64_t)__double_as_longlong(__longlong_as_double((long long)pre) + __longlong_as_double((long long)add));
+      slot_stats[lane] = lane <= ST_SUM_LEN ? as_int : as_real;
+    }
+  }
+}
+
+}  // namespace rdv
