@@ -714,14 +714,52 @@ int rdv_policy_create(const float* w1, const float* b1, const float* w2, const f
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RDV_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
   if (device < 0 || device >= count) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create: device %d out of range [0,%d)", device, count);
   DeviceGuard guard(device);
+  // The parameter block of csrc/rdv_policy.h: weight fragments in MFMA A-operand order, each weight split into three bf16 terms
+  // (w = hi + mid + lo to 24 bits), then the biases in accumulator order, exp(log_std) and log_std.  SB3 stores nn.Linear weights
+  // as [out, in], which is the A operand of the transposed product Y = W . X as it stands.
   std::vector<float> packed((size_t)kPolFloats, 0.0f);
-  // SB3 stores nn.Linear weights as [out, in]; the kernel wants them k-major ([in][out]) so that one input's 64 weights are contiguous
-  for (int j = 0; j < kPolHid; ++j) for (int k = 0; k < kPolIn; ++k) packed[kPolW1 + k * kPolHid + j] = w1[j * kPolIn + k];
-  for (int j = 0; j < kPolHid; ++j) packed[kPolB1 + j] = b1[j];
-  for (int j = 0; j < kPolHid; ++j) for (int k = 0; k < kPolHid; ++k) packed[kPolW2 + k * kPolHid + j] = w2[j * kPolHid + k];
-  for (int j = 0; j < kPolHid; ++j) packed[kPolB2 + j] = b2[j];
-  for (int j = 0; j < kPolOut; ++j) for (int k = 0; k < kPolHid; ++k) packed[kPolW3 + k * kPolOutPad + j] = w3[j * kPolHid + k];
-  for (int j = 0; j < kPolOut; ++j) { packed[kPolB3 + j] = b3[j]; packed[kPolStd + j] = std::exp(log_std[j]); }
+  uint16_t* frags = reinterpret_cast<uint16_t*>(packed.data());
+  auto bf16_rn = [](float x) -> uint16_t {   // round to nearest even
+    uint32_t u; std::memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  auto bf16_f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
+  auto put = [&](int frag0, int mt_count, int ks_count, int mt, int ks, int lane, int j, float wv) {
+    const uint16_t hi = bf16_rn(wv); const float r1 = wv - bf16_f(hi);
+    const uint16_t mid = bf16_rn(r1); const float r2 = r1 - bf16_f(mid);
+    const uint16_t term[3] = {hi, mid, bf16_rn(r2)};
+    for (int q = 0; q < 3; ++q) frags[((size_t)(frag0 + (q * mt_count + mt) * ks_count + ks) * 64 + (size_t)lane) * 8 + (size_t)j] = term[q];
+  };
+  for (int lane = 0; lane < 64; ++lane) {
+    const int r = lane & 31, h = lane >> 5;
+    for (int j = 0; j < 8; ++j) {
+      for (int mt = 0; mt < 2; ++mt) {
+        for (int s = 0; s < 2; ++s) {                                   // layer 1: natural k order (its B operand is built from obs rows)
+          const int k = 16 * s + 8 * h + j;
+          put(kPolW1Frag, 2, 2, mt, s, lane, j, k < kPolIn ? w1[(32 * mt + r) * kPolIn + k] : 0.0f);
+        }
+        for (int ks = 0; ks < 4; ++ks) {                                // layer 2: k order of an accumulator tile used as B operand
+          const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+          put(kPolW2Frag, 2, 4, mt, ks, lane, j, w2[(32 * mt + r) * kPolHid + k]);
+        }
+      }
+      for (int ks = 0; ks < 4; ++ks) {                                  // head: 6 output rows of a 32-row tile
+        const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+        put(kPolW3Frag, 1, 4, 0, ks, lane, j, r < kPolOut ? w3[r * kPolHid + k] : 0.0f);
+      }
+    }
+  }
+  for (int mt = 0; mt < 2; ++mt)
+    for (int h = 0; h < 2; ++h)
+      for (int e = 0; e < 16; ++e) {
+        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;                 // accumulator register e of lane half h -> row of the tile
+        packed[kPolB1 + (mt * 2 + h) * 16 + e] = b1[32 * mt + row];
+        packed[kPolB2 + (mt * 2 + h) * 16 + e] = b2[32 * mt + row];
+        if (mt == 0) packed[kPolB3 + h * 16 + e] = row < kPolOut ? b3[row] : 0.0f;
+      }
+  for (int j = 0; j < kPolOut; ++j) { packed[kPolStd + j] = std::exp(log_std[j]); packed[kPolLogStd + j] = log_std[j]; }
   RdvPolicyNet* p = new (std::nothrow) RdvPolicyNet();
   if (!p) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_policy_create: host allocation failed");
   p->magic = kPolicyMagic; p->device = device; p->weights = nullptr;

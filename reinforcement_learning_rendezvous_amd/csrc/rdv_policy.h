@@ -3,22 +3,25 @@
 //
 // It is the caller on the input side of the env step (SB3's collect_rollouts evaluates it once per step on the whole
 // batch); in PyTorch it is ~10 small kernels per step (3 GEMMs of 65,536 x {17,64} x {64,6}, biases, tanh, noise, clamp),
-// 60-70 us per step even when replayed from a HIP graph.  This IS a dense contraction, so it runs on the matrix cores — in
-// fp32, because bf16 would move the actions in the third decimal, i.e. change the trajectories:
-//   - a 512-thread workgroup owns 256 envs; each of its 8 waves computes the three layers for 32 envs as
-//     [32 envs x K] . [K x 64] with v_mfma_f32_32x32x2_f32 (exact fp32, accumulation in k order).  Eight waves put two on
-//     every SIMD, which hides one wave's LDS round trips and barrier-free hand-overs behind the other (a single 64-env wave per
-//     SIMD: 18-20 us per call).  Measured: the fp32-input MFMA runs at the fp32 VECTOR rate and its time ADDS to the vector work
-//     of the SIMD's waves (kernel = 6.9 us without the MFMAs + 5.3 us with them; static priorities or shifting the two waves against
-//     each other change nothing) — the matrix time of this kernel is a floor of 5.1 us at 65,536 envs, not something to hide;
-//   - the weights (30 KB, k-major) are copied to LDS once per workgroup; a B fragment is then one conflict-free
-//     ds_read_b32 per lane (lane l: W[2p + l/32][n0 + l%32]).  Fetching them from global memory inside the k loop, or
-//     through scalar loads into VALU FMAs (the first version), left a lone wave waiting on a cache round trip per k-pair;
-//   - the A operand (activations) comes from a wave-private LDS image [32][64] with row stride 65 (conflict-free for both the
-//     column reads of the A operand and the row writes of the C/D layout: col = l%32, row = (e&3) + 8(e>>2) + 4(l>>5));
-//     a layer's result has its column on the lane, so bias + tanh are per-lane constants, and it is written back to the
-//     image as the next layer's input;
-//   - observations in / actions out are staged through the same image so that global accesses are contiguous.
+// 60-70 us per step even when replayed from a HIP graph.  This IS a dense contraction, so it runs on the matrix cores, with
+// fp32-level accuracy (a bf16 or fp16 product alone would move the actions in the third decimal, i.e. change the trajectories):
+//
+//   - every fp32 operand x is split into three bf16 terms, x = hi + mid + lo exactly to 24 bits (hi = bf16(x), mid = bf16(x - hi),
+//     lo = bf16(x - hi - mid)); a product a.w is the sum of the six leading term products (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid,
+//     lo.hi — the dropped ones are below 2^-24 of it), each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  That is six
+//     bf16 MFMAs of 32 cycles per 16 k instead of eight fp32-input MFMAs of 64 cycles (0.37x the matrix time), and — measured on the
+//     first version of this kernel, which used v_mfma_f32_32x32x2_f32 — the fp32-input MFMA runs at the fp32 VECTOR rate and its
+//     time adds to the vector work of the SIMD's waves (6.9 us without the MFMAs, 12.2 us with them, whatever the wave arrangement,
+//     priorities or operand prefetch), while the bf16 MFMA is a pipe of its own that runs beside the tanh / split / noise work;
+//   - the layers are computed TRANSPOSED, Y[features][envs] = W . X: a wave owns 32 envs (the N of a 32x32 tile), the weights are the
+//     A operand, and a layer's accumulator tile — column (env) on the lane, rows (features) in the 16 registers — is directly the
+//     B operand of the next layer (cdna_hip_programming.md, "an accumulator tile as the next MFMA's operand"): activations never
+//     leave the registers, there is no LDS image, no transposition and no wave synchronisation between the layers.  The k order of
+//     such a fragment is permuted (element j of lane half h is feature 16s + 8(j>>2) + 4h + (j&3)); the host stores the weight
+//     fragments in that order, already split into bf16 terms, one 16-byte read per lane and fragment;
+//   - bias = accumulator initial value, tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32; the 64 -> 6 head is one more
+//     (padded) tile, so a lane ends up with 4 (lower half) or 2 (upper half) of its env's action means;
+//   - observations in / actions out are staged through LDS so that global accesses are contiguous.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -28,27 +31,31 @@
 
 namespace rdv {
 
-constexpr int kPolIn = 17, kPolInPad = 18, kPolHid = 64, kPolOut = 6, kPolOutPad = 32;
-// packed weights (floats), k-major: W1t[18][64] (row 17 = 0) | b1[64] | W2t[64][64] | b2[64] | W3t[64][32] (cols >= 6 = 0) | b3[32] | std[8]
-constexpr int kPolW1 = 0, kPolB1 = kPolW1 + kPolInPad * kPolHid, kPolW2 = kPolB1 + kPolHid, kPolB2 = kPolW2 + kPolHid * kPolHid,
-              kPolW3 = kPolB2 + kPolHid, kPolB3 = kPolW3 + kPolHid * kPolOutPad, kPolStd = kPolB3 + kPolOutPad,
-              kPolFloats = kPolStd + 8;
-static_assert(kPolFloats % 4 == 0, "the weight block is copied as float4");
-
-constexpr int kPolBlock = 512;                                   // 8 waves: waves w and w+4 share a SIMD
-constexpr int kPolWaveEnvs = 32;                                 // M of one MFMA tile
+constexpr int kPolIn = 17, kPolHid = 64, kPolOut = 6;
+constexpr int kPolWaveEnvs = 32;                                 // N of one MFMA tile = envs per wave
+constexpr int kPolBlock = 512;                                   // 8 waves
 constexpr int kPolBlockEnvs = (kPolBlock / 64) * kPolWaveEnvs;   // 256
-constexpr int kPolImgLd = kPolHid + 1;                           // row stride of an activation image (odd: see img_at)
-constexpr int kPolImgFloats = kPolWaveEnvs * kPolImgLd;          // 2080 floats = 8,320 B per wave
-constexpr int kPolLdsBytes = (kPolFloats + (kPolBlock / 64) * kPolImgFloats) * 4;   // 96,416 B of dynamic LDS: one workgroup per CU
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// LDS image of a layer's activations: [32 envs][64] floats with row stride 65.  ds_read_b32 / ds_write_b32 bank on (a/4) % 32
-// within each 32-lane half: the A-operand read (32 rows of one column per half) and the C/D write (32 columns of one row per half)
-// are then both conflict-free, and every address is a per-lane base plus a compile-time offset (no per-access address math; an
-// XOR swizzle of an unpadded image cost ~400 VALU instructions per wave, on the pipe that also does the tanh)
-__device__ __forceinline__ int img_at(int row, int col) { return row * kPolImgLd + col; }
+// Packed parameter block (built by rdv_policy_create, copied to LDS by every workgroup).  bf16 section: weight FRAGMENTS of
+// 64 lanes x 8 bf16 (1 KiB; lane l reads its 16 bytes at fragment*1024 + 16 l), term q in {hi, mid, lo}:
+//   layer 1, fragment (q*2 + mt)*2 + s      : lane (r, h), element j = W1_q[32 mt + r][16 s + 8 h + j]            (k >= 17: 0)
+//   layer 2, fragment 12 + (q*2 + mt)*4 + ks: lane (r, h), element j = W2_q[32 mt + r][perm(ks, h, j)]
+//   head,    fragment 36 + q*4 + ks         : lane (r, h), element j = W3_q[r][perm(ks, h, j)]                    (r >= 6: 0)
+// with perm(ks, h, j) = 32 (ks>>1) + 16 (ks&1) + 8 (j>>2) + 4 h + (j&3), the feature that element j of lane half h of registers
+// 8 (ks&1) .. 8 (ks&1) + 7 of accumulator tile ks>>1 holds.  fp32 section: the biases in accumulator order
+// ([mt][h][e] -> feature 32 mt + (e&3) + 8 (e>>2) + 4 h), exp(log_std) and log_std (entries 6, 7 zero).
+constexpr int kPolFragBytes = 64 * 16;
+constexpr int kPolW1Frag = 0, kPolW2Frag = 12, kPolW3Frag = 36, kPolFrags = 48;
+constexpr int kPolF32 = kPolFrags * kPolFragBytes / 4;           // float index of the fp32 section: 12288
+constexpr int kPolB1 = kPolF32, kPolB2 = kPolB1 + 64, kPolB3 = kPolB2 + 64, kPolStd = kPolB3 + 32, kPolLogStd = kPolStd + 8,
+              kPolFloats = kPolLogStd + 8;                       // 12,472 floats = 49,888 B
+static_assert(kPolFloats % 4 == 0, "the parameter block is copied as float4");
+// standalone kernel: parameters | per wave: observation rows [32][17] | per wave: action rows [32][6]
+constexpr int kPolObsStage = kPolWaveEnvs * kPolIn, kPolActStage = kPolWaveEnvs * kPolOut;
+constexpr int kPolLdsBytes = (kPolFloats + (kPolBlock / 64) * (kPolObsStage + kPolActStage)) * 4;   // 73,440 B: two workgroups per CU
 
 // tanh in fp32 as copysign(1 - 2 / (2^(2 log2(e) |x|) + 1), x): v_exp_f32 + v_rcp_f32 (1 ulp each) and four plain VALU ops.
 // Absolute error <= ~2.5e-7 everywhere (cancellation near 0 costs relative, not absolute, accuracy; what feeds the next layer's
@@ -74,147 +81,183 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// One dense layer of the wave's 32 envs on the matrix cores: out[32][NT*32] = act(in[32][K] . Wt[K][NT*32] + bias).
-// `in`: LDS rows of (odd) stride `ld` — the wave's image, or the staged observations; `Wt`, `bias`: the LDS copy of the weights
-// (k-major, KPAD rows, zero beyond K).  The result goes to the image `out` after every read of `in` (so out may alias in).
-template <int K, int KPAD, int LD, int NT, bool kTanh>
-__device__ __forceinline__ void dense_layer(const float* in, const float* Wt, int wld, const float* bias, float* out, int lane) {
-  const int r = lane & 31, kk = lane >> 5;
-  f32x16 d[NT];
+// x[j] = hi[j] + mid[j] + lo[j] to 24 bits; each subtraction is exact in fp32
+__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&t)[3]) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const float bc = bias[nt * 32 + r];                     // a lane's 16 accumulators share its column: start them at the bias
-#pragma unroll
-    for (int e = 0; e < 16; ++e) d[nt][e] = bc;
+  for (int j = 0; j < 8; ++j) {
+    const __bf16 hi = (__bf16)x[j];
+    const float r1 = x[j] - (float)hi;
+    const __bf16 mid = (__bf16)r1;
+    const float r2 = r1 - (float)mid;
+    t[0][j] = hi; t[1][j] = mid; t[2][j] = (__bf16)r2;
   }
-  // operands are read kDepth k-pairs ahead of the MFMAs that use them: read -> wait -> MFMA in lockstep leaves the matrix pipe idle
-  // for an LDS round trip per k-pair (the compiler does not hoist the reads by itself)
-  constexpr int P = KPAD / 2, kDepth = 4;
-  float av[P], bv[P][NT];
-  auto fetch = [&](int p) {
-    const int k = 2 * p + kk;                                 // A: lane l holds in[row l%32][2p + l/32]; B: Wt[2p + l/32][col l%32]
-    const bool kin = (KPAD == K) || (k < K);
-    av[p] = kin ? in[r * LD + k] : 0.0f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bv[p][nt] = Wt[k * wld + nt * 32 + r];
-  };
-#pragma unroll
-  for (int p = 0; p < kDepth && p < P; ++p) fetch(p);
-#pragma unroll
-  for (int p = 0; p < P; ++p) {
-    if (p + kDepth < P) fetch(p + kDepth);
-    __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead: the scheduler otherwise sinks each one next to its MFMA
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) d[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p], bv[p][nt], d[nt], 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  wave_fence();
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = nt * 32 + r;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int row = (e & 3) + 8 * (e >> 2) + 4 * kk;      // C/D layout: col = lane%32, row = (e&3) + 8(e>>2) + 4(lane>>5)
-      out[img_at(row, col)] = kTanh ? tanh_f32(d[nt][e]) : d[nt][e];
-    }
-  }
-  wave_fence();
 }
+
+// d += A . B for one 16-wide k-step, A (weights) and B (activations) given as their three bf16 terms: the six leading products,
+// smallest first
+__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 d) {
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], d, 0, 0, 0);
+  return d;
+}
+
+// One layer Y = W . X (+ bias) for the wave's 32 envs: MT row tiles of 32 output features, KS k-steps of 16 input features.
+// xb[ks]: the B fragments (three bf16 terms) of the input; frag0: index of the layer's first weight fragment, laid out
+// [q][mt][ks]; biasp: [mt][h][16] in accumulator order.
+template <int MT, int KS>
+__device__ __forceinline__ void layer(const float* w, int frag0, const float* biasp, const bf16x8 (&xb)[KS][3], int lane, f32x16 (&d)[MT]) {
+  const bf16x8* wf = reinterpret_cast<const bf16x8*>(w) + lane;
+  const int h = lane >> 5;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4) {
+      const float4 b = *reinterpret_cast<const float4*>(biasp + (mt * 2 + h) * 16 + 4 * e4);
+      d[mt][4 * e4 + 0] = b.x; d[mt][4 * e4 + 1] = b.y; d[mt][4 * e4 + 2] = b.z; d[mt][4 * e4 + 3] = b.w;
+    }
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      bf16x8 a[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) a[q] = wf[(frag0 + (q * MT + mt) * KS + ks) * 64];
+      d[mt] = mfma6(a, xb[ks], d[mt]);
+    }
+}
+
+// tanh of an accumulator tile, split into the B fragments of the next layer's k-steps 2 t, 2 t + 1 (registers 0..7 and 8..15)
+__device__ __forceinline__ void activate(const f32x16& d, bf16x8 (&lo_step)[3], bf16x8 (&hi_step)[3]) {
+  float x[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = tanh_f32(d[j]);
+  split3(x, lo_step);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = tanh_f32(d[8 + j]);
+  split3(x, hi_step);
+}
+
+// The actor for the wave's 32 envs.  `rows`: LDS, the wave's observations [32][17] (stride 17).  Lane (r = l & 31, h = l >> 5) gets
+// the action means of env r: components 0..3 in the lower half (h = 0), components 4, 5 in mean[0], mean[1] of the upper half.
+__device__ __forceinline__ void actor_means(const float* w, const float* rows, int lane, float (&mean)[4]) {
+  const int r = lane & 31, h = lane >> 5;
+  const float* row = rows + r * kPolIn;
+  bf16x8 x0[2][3];
+  {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = row[8 * h + j];            // k-step 0: features 8h + j
+    split3(x, x0[0]);
+    const float last = row[16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = 0.0f;
+    x[0] = h == 0 ? last : 0.0f;                                    // k-step 1: feature 16 only (17 inputs, padded to 32)
+    split3(x, x0[1]);
+  }
+  f32x16 d1[2];
+  layer<2, 2>(w, kPolW1Frag, w + kPolB1, x0, lane, d1);            // 17 -> 64
+  bf16x8 x1[4][3];
+  activate(d1[0], x1[0], x1[1]);
+  activate(d1[1], x1[2], x1[3]);
+  f32x16 d2[2];
+  layer<2, 4>(w, kPolW2Frag, w + kPolB2, x1, lane, d2);            // 64 -> 64
+  bf16x8 x2[4][3];
+  activate(d2[0], x2[0], x2[1]);
+  activate(d2[1], x2[2], x2[3]);
+  f32x16 d3[1];
+  layer<1, 4>(w, kPolW3Frag, w + kPolB3, x2, lane, d3);            // 64 -> 6 (rows 6..31 of the tile have zero weights)
+  mean[0] = d3[0][0]; mean[1] = d3[0][1]; mean[2] = d3[0][2]; mean[3] = d3[0][3];   // rows (e & 3) + 4 h
+}
+
+// mean -> sample (SB3 rollout form: mean + exp(log_std) N(0,1)) for this lane's components; returns the ENV's Gaussian log-density
+// log N(a; mean, std) summed over the 6 components (both lanes of an env get it).  Noise: Philox4x32-10 keyed by (seed, global env
+// id, counter); block 0 gives the normals of components 0..3, block 1 those of 4, 5 — a lane draws only its own half's block.
+__device__ __forceinline__ float actor_sample(const float* w, int lane, int deterministic, uint64_t seed, uint64_t id, uint64_t counter,
+                                              float (&a)[4]) {
+  const int h = lane >> 5;
+  float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (!deterministic) {
+    uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32), c2 = (uint32_t)counter, c3 = (uint32_t)(counter >> 32) * 2u + (uint32_t)h;
+    philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x504F4C49u);   // key tweak: not the reset stream
+    box_muller(c0, c1, z[0], z[1]);
+    box_muller(c2, c3, z[2], z[3]);
+  }
+  float lp = 0.0f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const bool valid = h == 0 || c < 2;                   // the upper half holds components 4, 5 only
+    a[c] = fmaf(w[kPolStd + 4 * h + c], z[c], a[c]);      // std entries 6, 7 are zero
+    lp += valid ? fmaf(-0.5f * z[c], z[c], -w[kPolLogStd + 4 * h + c]) : 0.0f;
+  }
+  return (lp + __shfl_xor(lp, 32)) - 5.5136312f;          // - 6/2 log(2 pi)
+}
+
+__device__ __forceinline__ float clip_action(float v) { return (v != v) ? v : fminf(fmaxf(v, -1.0f), 1.0f); }   // np.clip (NaN stays NaN)
 
 __global__ __launch_bounds__(kPolBlock) void policy_act_kernel(const float* __restrict__ W, const float* __restrict__ obs,
                                                                float* __restrict__ actions, int64_t n, int deterministic,
                                                                uint64_t seed, uint64_t counter, uint64_t env_id_offset) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [weights kPolFloats][8 x image 2048]
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [parameters][8 x obs rows][8 x action rows]
   float* w = lds;
   const int lane = threadIdx.x & 63;
   const int wv = threadIdx.x >> 6;
-  float* img = lds + kPolFloats + wv * kPolImgFloats;
+  float* rows = lds + kPolFloats + wv * kPolObsStage;
+  float* arows = lds + kPolFloats + (kPolBlock / 64) * kPolObsStage + wv * kPolActStage;
   const int64_t wave_base = ((int64_t)blockIdx.x * (kPolBlock / 64) + wv) * kPolWaveEnvs;
-  const int64_t rows = (n - wave_base) < kPolWaveEnvs ? (n - wave_base) : kPolWaveEnvs;   // <= 0 for trailing waves of the last workgroup
+  const int64_t nrows = (n - wave_base) < kPolWaveEnvs ? (n - wave_base) : kPolWaveEnvs;   // <= 0 for trailing waves of the last workgroup
 
-  // ---- weights -> LDS, once per workgroup (contiguous 16-byte-per-lane loads)
+  // ---- parameters -> LDS, once per workgroup (contiguous 16-byte-per-lane loads)
   for (int q = threadIdx.x; q < kPolFloats / 4; q += kPolBlock)
     *reinterpret_cast<float4*>(w + 4 * q) = *reinterpret_cast<const float4*>(W + 4 * q);
 
   // ---- observations [32,17] of this wave: contiguous loads -> plain LDS rows of stride 17 (missing rows = 0)
-  if (rows > 0) {
+  if (nrows > 0) {
     const float* src = obs + wave_base * kPolIn;
-    if (rows == kPolWaveEnvs) {
+    if (nrows == kPolWaveEnvs) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         const int q = k * 64 + lane;
-        if (q < kPolWaveEnvs * kPolIn / 4) *reinterpret_cast<float4*>(img + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+        if (q < kPolObsStage / 4) *reinterpret_cast<float4*>(rows + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
       }
     } else {
-      const int64_t valid = rows * kPolIn;
+      const int64_t valid = nrows * kPolIn;
       for (int j = 0; j < 9; ++j) {
         const int idx = j * 64 + lane;
-        if (idx < kPolWaveEnvs * kPolIn) img[idx] = idx < valid ? src[idx] : 0.0f;
+        if (idx < kPolObsStage) rows[idx] = idx < valid ? src[idx] : 0.0f;
       }
     }
   }
-  __syncthreads();   // the weights are in LDS (the only workgroup barrier; every wave reaches it)
-  if (rows <= 0) return;
+  __syncthreads();   // the parameters are in LDS (the only workgroup barrier; every wave reaches it)
+  if (nrows <= 0) return;
 
-  dense_layer<kPolIn, kPolInPad, kPolIn, 2, true>(img, w + kPolW1, kPolHid, w + kPolB1, img, lane);      // 17 -> 64, tanh
-  dense_layer<kPolHid, kPolHid, kPolImgLd, 2, true>(img, w + kPolW2, kPolHid, w + kPolB2, img, lane);              // 64 -> 64, tanh
-  // ---- 64 -> 6 on the vector pipe: as an MFMA tile it would spend 32 of the wave's 114 matrix instructions on 6 useful
-  // columns of 32, and the matrix pipe is the busier one.  Lane (env l%32, half l/32) sums its half of k (own image row:
-  // conflict-free; weight rows: one address per half = broadcast), the halves are added across lanes l and l+32.
-  float out[kPolOut];
-  const int er = lane & 31;
-  {
-    const int k0 = (lane >> 5) * (kPolHid / 2);
-    const float* h = img + er * kPolImgLd + k0;
-    const float* w3 = w + kPolW3 + k0 * kPolOutPad;
-#pragma unroll
-    for (int j = 0; j < kPolOut; ++j) out[j] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < kPolHid / 2; ++i) {
-      const float a = h[i];
-      const float4 wa = *reinterpret_cast<const float4*>(w3 + i * kPolOutPad);
-      const float2 wb = *reinterpret_cast<const float2*>(w3 + i * kPolOutPad + 4);
-      out[0] = fmaf(a, wa.x, out[0]); out[1] = fmaf(a, wa.y, out[1]); out[2] = fmaf(a, wa.z, out[2]);
-      out[3] = fmaf(a, wa.w, out[3]); out[4] = fmaf(a, wb.x, out[4]); out[5] = fmaf(a, wb.y, out[5]);
-    }
-#pragma unroll
-    for (int j = 0; j < kPolOut; ++j) out[j] = (out[j] + __shfl_xor(out[j], 32)) + w[kPolB3 + j];   // both lanes of a pair now hold env l%32
-  }
+  const int r = lane & 31, h = lane >> 5;
+  float a[4];
+  actor_means(w, rows, lane, a);
+  (void)actor_sample(w, lane, deterministic, seed, env_id_offset + (uint64_t)(wave_base + r), counter, a);
 
-  // ---- per env: mean (+ exp(log_std) * N(0,1)), clip (only the lower half stores)
-  if (!deterministic) {   // SB3 rollout form; noise from Philox4x32-10 keyed by (seed, global env id, counter)
-    const uint64_t id = env_id_offset + (uint64_t)(wave_base + er);
-    float z[8];
+  // ---- actions [32,6]: own components -> LDS rows -> contiguous 8-byte-per-lane stores
+  if (h == 0) {
 #pragma unroll
-    for (uint32_t b = 0; b < 2; ++b) {
-      uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32), c2 = (uint32_t)counter, c3 = (uint32_t)(counter >> 32) * 2u + b;
-      philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x504F4C49u);   // key tweak: not the reset stream
-      box_muller(c0, c1, z[4 * b + 0], z[4 * b + 1]);
-      box_muller(c2, c3, z[4 * b + 2], z[4 * b + 3]);
-    }
-#pragma unroll
-    for (int j = 0; j < kPolOut; ++j) out[j] = fmaf(w[kPolStd + j], z[j], out[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < kPolOut; ++j) out[j] = (out[j] != out[j]) ? out[j] : fminf(fmaxf(out[j], -1.0f), 1.0f);   // np.clip to the action Box (NaN stays NaN)
-
-  // ---- actions [32,6]: own row -> LDS -> contiguous 8-byte-per-lane stores
-  wave_fence();   // every lane has read its action means
-  if (lane < kPolWaveEnvs) {
-#pragma unroll
-    for (int j = 0; j < kPolOut; ++j) img[lane * kPolOut + j] = out[j];
+    for (int c = 0; c < 4; ++c) arows[r * kPolOut + c] = clip_action(a[c]);
+  } else {
+    arows[r * kPolOut + 4] = clip_action(a[0]);
+    arows[r * kPolOut + 5] = clip_action(a[1]);
   }
   wave_fence();
   {
     float* dst = actions + wave_base * kPolOut;
-    const int64_t valid = rows * kPolOut;
+    const int64_t valid = nrows * kPolOut;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int idx = k * 128 + lane * 2;
       if (idx + 1 < valid) {
-        *reinterpret_cast<float2*>(dst + idx) = *reinterpret_cast<const float2*>(img + idx);
+        *reinterpret_cast<float2*>(dst + idx) = *reinterpret_cast<const float2*>(arows + idx);
       } else if (idx < valid) {
-        dst[idx] = img[idx];
+        dst[idx] = arows[idx];
       }
     }
   }

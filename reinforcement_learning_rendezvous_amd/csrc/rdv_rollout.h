@@ -12,7 +12,7 @@
 //   - the current observations [256,17] and actions [256,6] are handed over through LDS; two workgroup barriers per step;
 //   - nothing is re-read from HBM between steps and there is no launch boundary: of the 19 us a policy_act + step pair takes
 //     at 65,536 envs, ~5 us are launch gaps and kernel entry/exit, and the state / observation round trips.
-// Phase A (actor waves): obs_t rows -> HBM; 17->64->64 on v_mfma_f32_32x32x2_f32 (rdv_policy.h), head, noise, clip -> LDS and HBM.
+// Phase A (actor waves): obs_t rows -> HBM; the actor of rdv_policy.h (bf16x3 MFMAs, register-resident), noise, clip -> LDS and HBM.
 // Phase B (env waves): transition, reward/done -> HBM, in-lane reset where an episode ended, obs_{t+1} -> LDS.
 // (Measured and dropped: preparing every env's next initial state in LDS while the env waves wait for the actor — the fp64 filler
 // work slows the actor waves of the same SIMD by as much as the in-lane reset costs; and drawing the noise before the layers in
@@ -26,10 +26,11 @@ constexpr int kRollEnvs = 256;                       // envs per workgroup
 constexpr int kRollEnvWaves = kRollEnvs / kWave;     // 4
 constexpr int kRollActorWaves = kRollEnvs / kPolWaveEnvs;   // 8
 constexpr int kRollBlock = (kRollEnvWaves + kRollActorWaves) * kWave;   // 768 threads
-// dynamic LDS: weights | 8 actor images | current observations [256][17] | current (clipped) actions [256][6] | 4 statistics slots
-constexpr int kRollLdsFloats = kPolFloats + kRollActorWaves * kPolImgFloats + kRollEnvs * RDV_OBS_DIM + kRollEnvs * RDV_ACT_DIM +
+// dynamic LDS: actor parameters | unclipped action rows [256][6] (staging) | current observations [256][17] | current (clipped)
+// actions [256][6] | 4 statistics slots
+constexpr int kRollLdsFloats = kPolFloats + kRollEnvs * RDV_ACT_DIM + kRollEnvs * RDV_OBS_DIM + kRollEnvs * RDV_ACT_DIM +
                                kRollEnvWaves * kStatWords * 2;
-constexpr int kRollLdsBytes = kRollLdsFloats * 4;    // 120,480 B: one workgroup per CU
+constexpr int kRollLdsBytes = kRollLdsFloats * 4;    // 80,096 B
 
 
 struct RolloutArgs {
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   using V = typename Vec4<ST>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* w = lds;
-  float* images = w + kPolFloats;
-  float* obs_cur = images + kRollActorWaves * kPolImgFloats;
+  float* act_raw = w + kPolFloats;
+  float* obs_cur = act_raw + kRollEnvs * RDV_ACT_DIM;
   float* act_cur = obs_cur + kRollEnvs * RDV_OBS_DIM;
   uint64_t* stat_lds = reinterpret_cast<uint64_t*>(act_cur + kRollEnvs * RDV_ACT_DIM);   // [4][16]: the rollout's statistics per env wave
   const DevParams& P = *Pp;   // scalar loads (see step_kernel)
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   const int r0 = a_wave * kPolWaveEnvs;
   const int64_t a_env0 = block_base + r0;
   const int64_t a_rows = env_role ? 0 : ((n - a_env0) < kPolWaveEnvs ? (n - a_env0) : kPolWaveEnvs);
-  float* img = images + (env_role ? 0 : a_wave) * kPolImgFloats;
+  float* araw = act_raw + (env_role ? 0 : r0) * RDV_ACT_DIM;   // this wave's staging rows
   const bool vec_rows = (n & 3) == 0;   // [t][n][17] rows of a wave start 16-byte aligned
 
   StepArgs SA;   // advance() only reads the diagnostics pointer (not used here)
@@ -133,57 +134,25 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
           }
         }
       }
-      const int er = lane & 31;
-      dense_layer<kPolIn, kPolInPad, kPolIn, 2, true>(xin, w + kPolW1, kPolHid, w + kPolB1, img, lane);     // 17 -> 64, tanh
-      dense_layer<kPolHid, kPolHid, kPolImgLd, 2, true>(img, w + kPolW2, kPolHid, w + kPolB2, img, lane);   // 64 -> 64, tanh
-      float out[kPolOut];
-      {  // 64 -> 6 on the vector pipe (rdv_policy.h)
-        const int k0 = (lane >> 5) * (kPolHid / 2);
-        const float* h = img + er * kPolImgLd + k0;
-        const float* w3 = w + kPolW3 + k0 * kPolOutPad;
+      const int er = lane & 31, eh = lane >> 5;
+      float a[4];
+      actor_means(w, xin, lane, a);
+      const float logp = actor_sample(w, lane, A.deterministic, A.noise_seed, A.env_id_offset + (uint64_t)(a_env0 + er),
+                                      A.noise_counter0 + (uint64_t)t, a);
+      // unclipped actions -> staging rows -> HBM; clipped actions -> LDS for the env waves
+      if (eh == 0) {
 #pragma unroll
-        for (int j = 0; j < kPolOut; ++j) out[j] = 0.0f;
-#pragma unroll
-        for (int q = 0; q < kPolHid / 2; ++q) {
-          const float a = h[q];
-          const float4 wa = *reinterpret_cast<const float4*>(w3 + q * kPolOutPad);
-          const float2 wb = *reinterpret_cast<const float2*>(w3 + q * kPolOutPad + 4);
-          out[0] = fmaf(a, wa.x, out[0]); out[1] = fmaf(a, wa.y, out[1]); out[2] = fmaf(a, wa.z, out[2]);
-          out[3] = fmaf(a, wa.w, out[3]); out[4] = fmaf(a, wb.x, out[4]); out[5] = fmaf(a, wb.y, out[5]);
+        for (int c = 0; c < 4; ++c) {
+          araw[er * RDV_ACT_DIM + c] = a[c];
+          act_cur[(r0 + er) * RDV_ACT_DIM + c] = clip_action(a[c]);
         }
+        if (A.log_prob && er < a_rows) A.log_prob[(int64_t)t * n + a_env0 + er] = logp;
+      } else {
 #pragma unroll
-        for (int j = 0; j < kPolOut; ++j) out[j] = (out[j] + __shfl_xor(out[j], 32)) + w[kPolB3 + j];
-      }
-      float logp = -5.5136312f;   // -6/2 * log(2 pi)
-      if (!A.deterministic) {
-        const uint64_t id = A.env_id_offset + (uint64_t)(a_env0 + er);
-        const uint64_t counter = A.noise_counter0 + (uint64_t)t;
-        float z[8];
-#pragma unroll
-        for (uint32_t b = 0; b < 2; ++b) {
-          uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32), c2 = (uint32_t)counter, c3 = (uint32_t)(counter >> 32) * 2u + b;
-          philox4x32_10(c0, c1, c2, c3, (uint32_t)A.noise_seed, (uint32_t)(A.noise_seed >> 32) ^ 0x504F4C49u);
-          box_muller(c0, c1, z[4 * b + 0], z[4 * b + 1]);
-          box_muller(c2, c3, z[4 * b + 2], z[4 * b + 3]);
+        for (int c = 0; c < 2; ++c) {
+          araw[er * RDV_ACT_DIM + 4 + c] = a[c];
+          act_cur[(r0 + er) * RDV_ACT_DIM + 4 + c] = clip_action(a[c]);
         }
-#pragma unroll
-        for (int j = 0; j < kPolOut; ++j) {
-          out[j] = fmaf(w[kPolStd + j], z[j], out[j]);
-          logp = fmaf(-0.5f * z[j], z[j], logp);
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < kPolOut; ++j) logp -= __logf(w[kPolStd + j]);
-      // raw actions -> the wave's image (staging) -> HBM; clipped actions -> LDS for the env waves
-      wave_fence();   // every lane is done with the image
-      if (lane < kPolWaveEnvs) {
-#pragma unroll
-        for (int j = 0; j < kPolOut; ++j) {
-          img[lane * kPolOut + j] = out[j];
-          const float c = (out[j] != out[j]) ? out[j] : fminf(fmaxf(out[j], -1.0f), 1.0f);   // np.clip (NaN stays NaN)
-          act_cur[(r0 + lane) * RDV_ACT_DIM + j] = c;
-        }
-        if (A.log_prob && lane < a_rows) A.log_prob[(int64_t)t * n + a_env0 + lane] = logp;
       }
       wave_fence();
       {
@@ -193,12 +162,13 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
         for (int k = 0; k < 2; ++k) {
           const int idx = k * 128 + lane * 2;
           if (idx + 1 < valid) {
-            *reinterpret_cast<float2*>(dst + idx) = *reinterpret_cast<const float2*>(img + idx);
+            *reinterpret_cast<float2*>(dst + idx) = *reinterpret_cast<const float2*>(araw + idx);
           } else if (idx < valid) {
-            dst[idx] = img[idx];
+            dst[idx] = araw[idx];
           }
         }
       }
+      wave_fence();   // the staging rows are free again before the next step writes them
     }
     __syncthreads();   // actions of step t are in LDS
     __syncthreads();   // observations of step t+1 are in LDS
