@@ -173,3 +173,23 @@ def test_nan_actions_poison_only_their_env():
     np.testing.assert_array_equal(_np(o)[keep], _np(o2)[keep])
     np.testing.assert_array_equal(_np(d)[keep], _np(d2)[keep])
     env.close(); clean.close()
+
+
+def test_vecenv_inertia_attributes_mirror_the_reference_env():
+    """`env.inertia`, `env.inv_inertia`, `env.inertia_target`, `env.inv_inertia_target` (rendezvous_env.py:75-80, :96-101) through the
+    SB3 get_attr / set_attr surface."""
+    from reinforcement_learning_rendezvous_amd.vec_env import RendezvousVecEnv
+    vec = RendezvousVecEnv(8, device="cuda:0", storage="f64")
+    iso = np.eye(3) * (100 * 2 / 12)
+    np.testing.assert_allclose(vec.get_attr("inertia")[0], iso)
+    np.testing.assert_allclose(vec.get_attr("inv_inertia_target", indices=[3])[0], np.linalg.inv(iso))
+    tensor = np.array([[14.0, 0.6, -0.4], [0.6, 18.5, 0.9], [-0.4, 0.9, 22.0]])
+    vec.set_attr("inertia", tensor)
+    vec.set_attr("inertia_target", [9.0, 16.0, 27.0])
+    np.testing.assert_allclose(vec.get_attr("inertia")[5], tensor)
+    np.testing.assert_allclose(vec.get_attr("inv_inertia")[0], np.linalg.inv(tensor))
+    np.testing.assert_allclose(vec.get_attr("inertia_target")[0], np.diag([9.0, 16.0, 27.0]))
+    obs = vec.reset()
+    obs2, rew, done, infos = vec.step(np.zeros((8, 6), np.float32))
+    assert obs2.shape == (8, 17) and np.isfinite(obs2).all() and len(infos) == 8
+    vec.close()
