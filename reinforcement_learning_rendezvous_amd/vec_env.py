@@ -91,8 +91,6 @@ class RendezvousVecEnv(_VecEnvBase):
         self._infos = [{} for _ in range(self.num_envs)]
         self._dirty = []
         self._t_start = time.time()
-        pin = torch.cuda.is_available() and engine.device.type == "cuda"
-        self._act_host = torch.zeros((self.num_envs, 6), dtype=torch.float32, pin_memory=pin)
 
     # ------------------------------------------------------------------------------------------------ VecEnv API
     def reset(self):
@@ -101,36 +99,47 @@ class RendezvousVecEnv(_VecEnvBase):
     def step_async(self, actions):
         a = np.asarray(actions, dtype=np.float32)
         assert a.shape == (self.num_envs, 6), f"expected actions of shape ({self.num_envs}, 6), got {a.shape}"   # :168
-        self._act_host.copy_(torch.from_numpy(a))
-        self._actions = self._act_host.to(self.batch.device, non_blocking=True)
+        # straight from the caller's array: staging through a pinned buffer costs more than it saves here (CPU writes into
+        # pinned host memory run at ~150 MB/s on this platform: 10 ms for 65,536 x 6 floats)
+        self._actions = torch.from_numpy(np.ascontiguousarray(a)).to(self.batch.device)
 
     def step_wait(self):
         b = self.batch
         obs, rew, done = b.step(self._actions)
+        # (measured and dropped: pinned staging buffers with non-blocking copies and one synchronisation — 2x slower here than
+        # three plain .cpu() calls)
         obs_h, rew_h = obs.cpu().numpy(), rew.cpu().numpy()
         done_h = done.cpu().numpy().astype(bool)
+        infos = self._infos
         for i in self._dirty:           # only the entries written last step are touched: O(#done), not O(N)
-            self._infos[i] = {}
+            infos[i] = {}
         self._dirty = []
         idx = np.flatnonzero(done_h)
         if idx.size:
-            t_obs = b.terminal_obs.cpu().numpy()
-            ep_r, ep_l = b.episode_return.cpu().numpy(), b.episode_length.cpu().numpy()
-            reason = b.done_reason.cpu().numpy()
+            # the rows of the finished envs are gathered on the device and cross PCIe once; the dicts are built from Python
+            # lists (tolist) rather than NumPy scalars: this loop is the cost of the SB3 boundary at 65,536 envs
+            sel = torch.from_numpy(idx).to(b.device)
+            packed = torch.cat([b.terminal_obs.index_select(0, sel),
+                                b.episode_return.index_select(0, sel).unsqueeze(1),
+                                b.episode_length.index_select(0, sel).to(torch.float32).unsqueeze(1),
+                                b.done_reason.index_select(0, sel).to(torch.float32).unsqueeze(1)], dim=1).cpu().numpy()
+            t_obs = np.ascontiguousarray(packed[:, :17])
+            ep_r, ep_l = packed[:, 17].tolist(), packed[:, 18].astype(np.int64).tolist()
+            codes = packed[:, 19].astype(np.int64).tolist()
             now = round(time.time() - self._t_start, 6)
-            for i in idx:
-                code = int(reason[i])
-                self._infos[i] = {
-                    "terminal_observation": t_obs[i].copy(),
-                    "episode": {"r": float(ep_r[i]), "l": int(ep_l[i]), "t": now},      # SB3 Monitor
-                    "end_reason": _END_REASONS[code & 7], "collided": bool(code & 16), "success": bool(code & 32),
-                }
-                if not self.quiet:                                                       # :376-382
-                    dist = float(np.linalg.norm(t_obs[i][0:3]) * b.params.max_axial_distance)
+            idx_list = idx.tolist()
+            reasons = [_END_REASONS[c & 7] for c in codes]
+            for i, row, r, l, why, c in zip(idx_list, t_obs, ep_r, ep_l, reasons, codes):
+                infos[i] = {"terminal_observation": row, "episode": {"r": r, "l": l, "t": now},      # SB3 Monitor
+                            "end_reason": why, "collided": (c & 16) != 0, "success": (c & 32) != 0}
+            if not self.quiet:                                                           # :376-382
+                for j in range(len(idx_list)):
+                    code = codes[j]
+                    dist = float(np.linalg.norm(t_obs[j][0:3]) * b.params.max_axial_distance)
                     print("Episode end | r = " + str(round(dist, 2)).rjust(5) + " | t = " +
-                          str(round(int(ep_l[i]) * b.params.dt, 3)).rjust(4) + " | " + _END_REASONS[code & 7].center(8) +
+                          str(round(ep_l[j] * b.params.dt, 3)).rjust(4) + " | " + _END_REASONS[code & 7].center(8) +
                           " | " + ("Collided" if code & 16 else " "))
-            self._dirty = idx.tolist()
+            self._dirty = idx_list
         return obs_h, rew_h, done_h, self._infos
 
     def step(self, actions):
