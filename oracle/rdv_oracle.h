@@ -12,13 +12,17 @@
  *   (1) per-step transition tuples recorded from the unmodified reference env run in the build container
  *       (tests/golden/make_golden.py, tests/golden/steps_*.npz),
  *   (2) the reference's own published per-trajectory Monte Carlo table
- *       (results/data_monte_carlo_results_mlp.xlsx -> tests/golden/monte_carlo_mlp.npz),
- *   (3) the known-answer cases of the reference's verification/ scripts.
+ *       (results/data_monte_carlo_results_mlp.xlsx -> tests/golden/mc_published_xlsx.npz),
+ *   (3) the known-answer cases of the reference's verification/ scripts,
+ *   (4) direct calls of the reference's utils functions and of scipy's solve_ivp(RK45) on its right-hand side with random
+ *       inertia tensors and torques (tests/golden/kat_reference_functions.npz, kat_rigid_body.npz), and reference
+ *       transitions with anisotropic bodies (tests/golden/steps_F_rigid.npz).
  *
  * The one deliberate departure from the reference: the two scipy RK45 attitude integrations
  * (rendezvous_env.py:561-570, :588-597) are replaced by the exact solution of the same ODE for the
  * reference's isotropic inertia and zero torque (orc_integrate_attitude).  ORC_INTEGRATOR_RK45 keeps a
- * Dormand-Prince 5(4) integrator with scipy's step control for cross-checking that substitution.
+ * Dormand-Prince 5(4) integrator with scipy's step control for cross-checking that substitution, and
+ * ORC_INTEGRATOR_GENERAL runs it on the full right-hand side (any inertia tensor, body torques: OrcRigidBody).
  */
 #ifndef RDV_ORACLE_H_
 #define RDV_ORACLE_H_
