@@ -244,6 +244,16 @@ int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, in
                    uint64_t counter, uint64_t env_id_offset, void* stream);
 
 /*
+ * The critic of the same checkpoint (mlp_extractor.value_net.{0,2} [64,17], [64,64] + value_net [1,64]; SB3 MlpPolicy keeps
+ * separate actor and critic trunks): values [n] for observations [n,17], e.g. for the [T*N,17] rows of a rollout (SB3's
+ * compute_returns_and_advantage needs them).  Same kernel structure and accuracy as the actor.  The handle type is shared;
+ * rdv_policy_destroy frees it.
+ */
+int rdv_critic_create(const float* w1_host, const float* b1_host, const float* w2_host, const float* b2_host,
+                      const float* w3_host, const float* b3_host, int device, rdv_policy* out);
+int rdv_policy_value(rdv_policy critic, const float* obs, float* values, int64_t n, void* stream);
+
+/*
  * Closed-loop rollout collection in ONE launch: for t in [0, n_steps): a_t ~ actor(obs_t); obs_{t+1}, r_t, done_t =
  * step(clip(a_t)) — the inner loop of SB3's OnPolicyAlgorithm.collect_rollouts (what model.learn, main.py:114, spends its
  * env time in) with the actor above, writing the rows SB3's RolloutBuffer.add receives.  Results are those of

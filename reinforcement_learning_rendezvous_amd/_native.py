@@ -26,7 +26,7 @@ SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_va
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
            "rdv_set_kernel_variant", "rdv_rigid_body_default", "rdv_set_rigid_body", "rdv_get_rigid_body",
            "rdv_reset", "rdv_step", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_observe", "rdv_diagnose",
-           "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act", "rdv_rollout"]
+           "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act", "rdv_critic_create", "rdv_policy_value", "rdv_rollout"]
 
 
 class RdvError(RuntimeError):
@@ -125,6 +125,8 @@ def lib():
         "rdv_policy_create": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]),
         "rdv_policy_destroy": (C.c_int, [vp]),
         "rdv_policy_act": (C.c_int, [vp, vp, vp, i64, C.c_int, u64, u64, u64, vp]),
+        "rdv_critic_create": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]),
+        "rdv_policy_value": (C.c_int, [vp, vp, vp, i64, vp]),
         "rdv_rollout": (C.c_int, [vp, vp, i32, C.POINTER(RolloutOut), C.c_int, u64, u64, vp]),
     }
     for name, (res, args) in sig.items():

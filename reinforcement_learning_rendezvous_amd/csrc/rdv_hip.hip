@@ -703,13 +703,15 @@ int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -
 struct RdvPolicyNet {
   uint32_t magic;
   int device;
-  float* weights;   // device, kPolFloats floats in the packed k-major layout
+  float* weights;   // device, kPolFloats floats: the parameter block of csrc/rdv_policy.h
+  int out_dim;      // 6: the actor (rdv_policy_create), 1: the critic (rdv_critic_create)
 };
 static constexpr uint32_t kPolicyMagic = 0x52445650u;   // "RDVP"
 
-int rdv_policy_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
-                      const float* log_std, int device, rdv_policy* out) {
-  if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !log_std || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create: null argument");
+// A 17-64-64-out_dim tanh MLP of the checkpoint (out_dim <= 6) as a parameter block on the device
+static int create_mlp(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* log_std, int out_dim, int device, rdv_policy* out) {
+  if (!w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create / rdv_critic_create: null argument");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RDV_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
   if (device < 0 || device >= count) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create: device %d out of range [0,%d)", device, count);
@@ -747,7 +749,7 @@ int rdv_policy_create(const float* w1, const float* b1, const float* w2, const f
       }
       for (int ks = 0; ks < 4; ++ks) {                                  // head: 6 output rows of a 32-row tile
         const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
-        put(kPolW3Frag, 1, 4, 0, ks, lane, j, r < kPolOut ? w3[r * kPolHid + k] : 0.0f);
+        put(kPolW3Frag, 1, 4, 0, ks, lane, j, r < out_dim ? w3[r * kPolHid + k] : 0.0f);
       }
     }
   }
@@ -757,19 +759,30 @@ int rdv_policy_create(const float* w1, const float* b1, const float* w2, const f
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;                 // accumulator register e of lane half h -> row of the tile
         packed[kPolB1 + (mt * 2 + h) * 16 + e] = b1[32 * mt + row];
         packed[kPolB2 + (mt * 2 + h) * 16 + e] = b2[32 * mt + row];
-        if (mt == 0) packed[kPolB3 + h * 16 + e] = row < kPolOut ? b3[row] : 0.0f;
+        if (mt == 0) packed[kPolB3 + h * 16 + e] = row < out_dim ? b3[row] : 0.0f;
       }
-  for (int j = 0; j < kPolOut; ++j) { packed[kPolStd + j] = std::exp(log_std[j]); packed[kPolLogStd + j] = log_std[j]; }
+  if (log_std) for (int j = 0; j < out_dim; ++j) { packed[kPolStd + j] = std::exp(log_std[j]); packed[kPolLogStd + j] = log_std[j]; }
   RdvPolicyNet* p = new (std::nothrow) RdvPolicyNet();
   if (!p) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_policy_create: host allocation failed");
-  p->magic = kPolicyMagic; p->device = device; p->weights = nullptr;
+  p->magic = kPolicyMagic; p->device = device; p->weights = nullptr; p->out_dim = out_dim;
   hipError_t err = hipMalloc(&p->weights, packed.size() * sizeof(float));
   if (err == hipSuccess) err = hipMemcpy(p->weights, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice);
-  // the kernel keeps the weights and 8 activation images in 93 KiB of dynamic LDS (above the 64 KiB default limit)
+  // the kernels keep the parameter block and the staged rows in 72 KiB of dynamic LDS (above the 64 KiB default limit)
   if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(policy_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPolLdsBytes);
+  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(policy_value_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPolLdsBytes);
   if (err != hipSuccess) { if (p->weights) (void)hipFree(p->weights); delete p; return fail(RDV_ERR_HIP, "rdv_policy_create: %s", hipGetErrorString(err)); }
   *out = p;
   return RDV_OK;
+}
+
+int rdv_policy_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      const float* log_std, int device, rdv_policy* out) {
+  if (!log_std) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create: null argument");
+  return create_mlp(w1, b1, w2, b2, w3, b3, log_std, kPolOut, device, out);
+}
+int rdv_critic_create(const float* w1, const float* b1, const float* w2, const float* b2, const float* w3, const float* b3,
+                      int device, rdv_policy* out) {
+  return create_mlp(w1, b1, w2, b2, w3, b3, nullptr, 1, device, out);
 }
 
 int rdv_policy_destroy(rdv_policy p) {
@@ -785,6 +798,7 @@ int rdv_policy_destroy(rdv_policy p) {
 int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, int deterministic, uint64_t seed, uint64_t counter,
                    uint64_t env_id_offset, void* stream) {
   if (!p || p->magic != kPolicyMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_policy");
+  if (p->out_dim != kPolOut) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_act: this handle is a critic (rdv_critic_create)");
   if (!obs || !actions || n <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_act: obs, actions and a positive n are required");
   if ((reinterpret_cast<uintptr_t>(obs) & 15) || (reinterpret_cast<uintptr_t>(actions) & 15))
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_act: obs and actions must be 16-byte aligned");
@@ -795,10 +809,23 @@ int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, in
   return RDV_OK;
 }
 
+int rdv_policy_value(rdv_policy p, const float* obs, float* values, int64_t n, void* stream) {
+  if (!p || p->magic != kPolicyMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_policy");
+  if (p->out_dim != 1) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_value: this handle is an actor (rdv_policy_create)");
+  if (!obs || !values || n <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_value: obs, values and a positive n are required");
+  if (reinterpret_cast<uintptr_t>(obs) & 15) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_value: obs must be 16-byte aligned");
+  DeviceGuard guard(p->device);
+  hipLaunchKernelGGL(policy_value_kernel, dim3((unsigned)((n + kPolBlockEnvs - 1) / kPolBlockEnvs)), dim3(kPolBlock), kPolLdsBytes,
+                     static_cast<hipStream_t>(stream), p->weights, obs, values, n);
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
+}
+
 int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut* out, int deterministic, uint64_t noise_seed,
                 uint64_t noise_counter0, void* stream) {
   RDV_CHECK_HANDLE(h);
   if (!p || p->magic != kPolicyMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_policy");
+  if (p->out_dim != kPolOut) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: this handle is a critic (rdv_critic_create)");
   if (p->device != h->device) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: the policy lives on device %d, the envs on device %d", p->device, h->device);
   if (n_steps <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: n_steps must be positive (got %d)", n_steps);
   if (!out || !out->obs || !out->actions || !out->reward || !out->done || !out->last_obs)

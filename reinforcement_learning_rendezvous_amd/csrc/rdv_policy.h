@@ -263,4 +263,40 @@ __global__ __launch_bounds__(kPolBlock) void policy_act_kernel(const float* __re
   }
 }
 
+// The critic of the same checkpoint (mlp_extractor.value_net 17-64-64 tanh + value_net 64 -> 1): the same parameter block with
+// one output row; values [n] for observations [n,17] (e.g. the [T*N,17] rows a rollout produced, for SB3's GAE).
+__global__ __launch_bounds__(kPolBlock) void policy_value_kernel(const float* __restrict__ W, const float* __restrict__ obs,
+                                                                 float* __restrict__ values, int64_t n) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* w = lds;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
+  float* rows = lds + kPolFloats + wv * kPolObsStage;
+  const int64_t wave_base = ((int64_t)blockIdx.x * (kPolBlock / 64) + wv) * kPolWaveEnvs;
+  const int64_t nrows = (n - wave_base) < kPolWaveEnvs ? (n - wave_base) : kPolWaveEnvs;
+  for (int q = threadIdx.x; q < kPolFloats / 4; q += kPolBlock)
+    *reinterpret_cast<float4*>(w + 4 * q) = *reinterpret_cast<const float4*>(W + 4 * q);
+  if (nrows > 0) {
+    const float* src = obs + wave_base * kPolIn;
+    if (nrows == kPolWaveEnvs) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int q = k * 64 + lane;
+        if (q < kPolObsStage / 4) *reinterpret_cast<float4*>(rows + 4 * q) = *reinterpret_cast<const float4*>(src + 4 * q);
+      }
+    } else {
+      const int64_t valid = nrows * kPolIn;
+      for (int j = 0; j < 9; ++j) {
+        const int idx = j * 64 + lane;
+        if (idx < kPolObsStage) rows[idx] = idx < valid ? src[idx] : 0.0f;
+      }
+    }
+  }
+  __syncthreads();
+  if (nrows <= 0) return;
+  float v[4];
+  actor_means(w, rows, lane, v);
+  if (lane < nrows) values[wave_base + lane] = v[0];   // lanes 0..31: row 0 of the head tile of env l
+}
+
 }  // namespace rdv

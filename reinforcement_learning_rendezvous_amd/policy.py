@@ -15,6 +15,8 @@ import torch
 
 _KEYS = ["mlp_extractor.policy_net.0.weight", "mlp_extractor.policy_net.0.bias", "mlp_extractor.policy_net.2.weight",
          "mlp_extractor.policy_net.2.bias", "action_net.weight", "action_net.bias", "log_std"]
+_VKEYS = ["mlp_extractor.value_net.0.weight", "mlp_extractor.value_net.0.bias", "mlp_extractor.value_net.2.weight",
+          "mlp_extractor.value_net.2.bias", "value_net.weight", "value_net.bias"]     # the critic trunk + head of the same checkpoint
 
 
 class MlpPolicy(torch.nn.Module):
@@ -24,11 +26,17 @@ class MlpPolicy(torch.nn.Module):
         self.noise_seed = int(seed)     # HIP backend: Philox key of the exploration noise; the call counter is the step index
         self.noise_env_offset = 0       # HIP backend: global index of row 0 (sharded batches: noise keyed by global env id)
         self._hip = {}                  # device index -> rdv_policy handle
+        self._hip_critic = {}           # device index -> rdv_policy handle of the critic
         self._calls = 0
         self.l1 = torch.nn.Linear(obs_dim, hidden)
         self.l2 = torch.nn.Linear(hidden, hidden)
         self.l3 = torch.nn.Linear(hidden, act_dim)
         self.log_std = torch.nn.Parameter(torch.zeros(act_dim))
+        # critic (SB3 MlpPolicy: separate 17-64-64 tanh trunk + 64 -> 1 head); zero-initialised when the weights have none
+        self.v1 = torch.nn.Linear(obs_dim, hidden)
+        self.v2 = torch.nn.Linear(hidden, hidden)
+        self.v3 = torch.nn.Linear(hidden, 1)
+        self.has_critic = False
         if weights is None:
             # random init of the same architecture (bench.py when the checkpoint fixture is absent)
             g = torch.Generator().manual_seed(seed)
@@ -42,6 +50,12 @@ class MlpPolicy(torch.nn.Module):
                 self.l2.weight.copy_(w[_KEYS[2]]); self.l2.bias.copy_(w[_KEYS[3]])
                 self.l3.weight.copy_(w[_KEYS[4]]); self.l3.bias.copy_(w[_KEYS[5]])
                 self.log_std.copy_(w[_KEYS[6]])
+                if all(k in weights for k in _VKEYS):
+                    v = {k: torch.as_tensor(np.asarray(weights[k]), dtype=torch.float32) for k in _VKEYS}
+                    self.v1.weight.copy_(v[_VKEYS[0]]); self.v1.bias.copy_(v[_VKEYS[1]])
+                    self.v2.weight.copy_(v[_VKEYS[2]]); self.v2.bias.copy_(v[_VKEYS[3]])
+                    self.v3.weight.copy_(v[_VKEYS[4]]); self.v3.bias.copy_(v[_VKEYS[5]])
+                    self.has_critic = True
         for p in self.parameters():
             p.requires_grad_(False)
 
@@ -85,12 +99,36 @@ class MlpPolicy(torch.nn.Module):
         self._calls += 1
         return out
 
-    def close(self):
-        if self._hip:
+    @torch.no_grad()
+    def value(self, obs, out=None):
+        """The critic's value estimate for observations [..., 17] (SB3 ``policy.predict_values``): one HIP kernel for CUDA
+        float32 observations (rdv_policy_value), the PyTorch modules otherwise / with ``backend="torch"``."""
+        shape = obs.shape[:-1]
+        flat = obs.reshape(-1, 17)
+        if self.backend != "torch" and flat.is_cuda and flat.dtype == torch.float32:
             from . import _native as N
-            for h in self._hip.values():
+            flat = flat.contiguous()
+            idx = flat.device.index if flat.device.index is not None else torch.cuda.current_device()
+            if idx not in self._hip_critic:
+                w = [t.detach().to("cpu", torch.float32).contiguous() for t in
+                     (self.v1.weight, self.v1.bias, self.v2.weight, self.v2.bias, self.v3.weight, self.v3.bias)]
+                h = C.c_void_p()
+                N.check(N.lib().rdv_critic_create(*[C.c_void_p(t.data_ptr()) for t in w], idx, C.byref(h)))
+                self._hip_critic[idx] = h
+            if out is None:
+                out = torch.empty((flat.shape[0],), dtype=torch.float32, device=flat.device)
+            stream = C.c_void_p(torch.cuda.current_stream(flat.device).cuda_stream)
+            N.check(N.lib().rdv_policy_value(self._hip_critic[idx], C.c_void_p(flat.data_ptr()), C.c_void_p(out.data_ptr()),
+                                             flat.shape[0], stream))
+            return out.reshape(shape)
+        return self.v3(torch.tanh(self.v2(torch.tanh(self.v1(flat))))).reshape(shape)
+
+    def close(self):
+        if self._hip or self._hip_critic:
+            from . import _native as N
+            for h in list(self._hip.values()) + list(self._hip_critic.values()):
                 N.lib().rdv_policy_destroy(h)
-            self._hip = {}
+            self._hip, self._hip_critic = {}, {}
 
     @torch.no_grad()
     def act(self, obs, deterministic=True, generator=None, out=None):

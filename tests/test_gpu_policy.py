@@ -78,3 +78,36 @@ def test_policy_kernel_drives_the_env_like_the_torch_policy():
     assert abs(int(res["succeeded"].sum()) - 545) <= 2 and abs(int(res["collided"].sum()) - 166) <= 2
     assert hip._calls >= 60
     hip.close()
+
+
+def test_critic_values_match_torch_reference():
+    """rdv_policy_value (the checkpoint's critic, same kernel structure as the actor) against the PyTorch modules.  The value
+    head is badly conditioned in fp32 (values of this checkpoint reach +-1500 and the PyTorch fp32 result itself is 2e-3 away
+    from an fp64 evaluation), so both are compared with the fp64 evaluation of the same modules: the kernel must be within
+    2e-6 of the largest value, and not worse than the fp32 reference."""
+    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+    hip, ref = _policies()
+    ref.backend = "torch"
+    ref64 = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz")).double().to("cuda:0")
+    assert hip.has_critic
+
+    def v64(o):
+        o = o.double().reshape(-1, 17)
+        return ref64.v3(torch.tanh(ref64.v2(torch.tanh(ref64.v1(o))))).reshape(-1)
+
+    gen = torch.Generator(device="cuda:0").manual_seed(1)
+    for n in (1, 31, 33, 257, 65536):
+        obs = (torch.rand((n, 17), device="cuda:0", generator=gen) * 2 - 1).contiguous()
+        v, w, t = hip.value(obs), ref.value(obs), v64(obs)
+        assert v.shape == (n,) and v.dtype == torch.float32
+        scale = float(t.abs().max())
+        err_hip, err_ref = float((v.double() - t).abs().max()), float((w.double() - t).abs().max())
+        assert err_hip <= 2e-6 * max(scale, 10.0), (n, err_hip, scale)
+        assert err_hip <= 1.5 * err_ref + 1e-5 * max(scale, 1.0) * 1e-1, (n, err_hip, err_ref)
+    g = load_golden("steps_B_mc_policy.npz")
+    obs = torch.from_numpy(g["obs_ret"]).cuda()                       # [T, E, 17]: the shape a rollout buffer has
+    v, t = hip.value(obs), v64(obs).reshape(obs.shape[:2])
+    assert v.shape == obs.shape[:2]
+    assert float((v.double() - t).abs().max()) <= 2e-6 * float(t.abs().max())
+    assert float(t.abs().max()) > 10.0
+    hip.close(); ref.close()
