@@ -636,7 +636,6 @@ struct RdvEnvBatch {
   int32_t tape_depth;
   int variant;       // RdvKernelVariant
   RdvRigidBody body; // rdv_set_rigid_body
-  bool rollout_ready;   // the rollout kernel's dynamic-LDS limit has been raised on this device
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
@@ -835,11 +834,6 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: call rdv_reset first (state is undefined until reset(), as in the reference)");
   if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_policy_act + rdv_step");
   DeviceGuard guard(h->device);
-  if (!h->rollout_ready) {   // 117 KiB of dynamic LDS (above the 64 KiB default limit)
-    RDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes));
-    RDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes));
-    h->rollout_ready = true;
-  }
   RolloutArgs A;
   A.ws = h->ws; A.stats = h->stats; A.obs = out->obs; A.actions = out->actions; A.reward = out->reward; A.done = out->done;
   A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.seed = h->seed;
@@ -870,7 +864,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   if (!h) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_create: host allocation failed");
   h->magic = kMagic; h->params = *params; derive_params(*params, h->dev);
   (void)rdv_rigid_body_default(&h->body); h->general = false; apply_rigid_body(h);
-  h->rollout_ready = false;
+
   h->n = n_envs; h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
@@ -891,6 +885,9 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
     err = hipMemcpy(h->acos_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice);
   }
   if (err == hipSuccess) err = hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice);
+  // the rollout kernel uses 78 KiB of dynamic LDS (above the 64 KiB default limit); raised here, outside any stream capture
+  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes);
+  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes);
   if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset of the workspace failed: %s", hipGetErrorString(err)); }
   h->host_slots.resize((size_t)(n_waves(n_envs) * kStatWords));
   *out = h;
