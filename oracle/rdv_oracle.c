@@ -364,6 +364,11 @@ void orc_integrate_attitude(double q[4], double w[3], double dt, int integrator)
   }
   /* Exact solution: inertia = c*Identity and torque = 0 make w x (I w) = 0 (dynamics.py:169-171), so w is constant and
    * q_dot = 0.5 * Omega(w) q (dynamics.py:137-151) integrates to the right-multiplication q (x) [cos(|w|dt/2), w_hat sin(|w|dt/2)]. */
+  /* The right-hand side normalises q before differentiating it (dynamics.py:109, :134) but the integrated state is the quaternion
+   * as given: for |q| = rho the solution keeps its norm and turns at w / rho.  Every step ends with a normalisation (:574, :601),
+   * so rho differs from 1 only for a state injected from outside (monte_carlo.py:107-112 normalises first, :66-67). */
+  const double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (fabs(n2 - 1.0) > 1e-6) dt = dt / sqrt(n2);
   const double wn = norm3(w);
   const double half = 0.5 * wn * dt;
   double dq[4];

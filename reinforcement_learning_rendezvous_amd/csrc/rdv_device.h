@@ -163,8 +163,20 @@ __device__ __forceinline__ void matTvec(const double* m, const double* v, double
 
 // rendezvous_env.py:552-604 with the reference's isotropic inertia and zero torque: w is constant and
 // q(t+dt) = normalize(q (x) [cos(|w|dt/2), w_hat sin(|w|dt/2)])  (body-frame rate: right multiplication, dynamics.py:137-151)
+// The reference's right-hand side normalises q before differentiating it (dynamics.py:109, :134) while the integrated state is the
+// quaternion as given: for |q| = rho the solution keeps its norm and turns at w / rho.  Every step ends with a normalisation, so
+// rho != 1 only in the first step after a state was injected from outside (rdv_set_state): kRaw builds handle it, the kernels of
+// every other step do not pay for the test.
+template <bool kRaw = false>
 __device__ __forceinline__ void integrate_attitude(double* q, const double* w, double half_dt) {
-  const double u = dot3(w, w) * (half_dt * half_dt);     // (|w| dt/2)^2
+  double u = dot3(w, w) * (half_dt * half_dt);           // (|w| dt/2)^2
+  if (kRaw) {
+    const double n2 = fma(q[3], q[3], fma(q[2], q[2], fma(q[1], q[1], q[0] * q[0])));
+    if (fabs(n2 - 1.0) > 1e-6) {
+      half_dt *= rsqrt64(n2);
+      u = (dot3(w, w) * half_dt) * half_dt;              // in this order: a body at rest stays exact for any |q| > 0
+    }
+  }
   double c, sc;
   cos_sinc(u, c, sc);
   const double k = sc * half_dt;                          // sin(|w|dt/2)/|w|
@@ -571,7 +583,7 @@ struct StepResult {
 };
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
-template <typename ST, bool kLazy, bool kGeneral = false>
+template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false>
 __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d) {
   const ST tag = ST(0);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
@@ -599,8 +611,8 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
 #pragma unroll
     for (int i = 0; i < 3; ++i) e.wt[i] = canon(e.wt[i], tag);
   } else {
-    integrate_attitude(e.qc, e.wc, P.half_dt);   // :181
-    integrate_attitude(e.qt, e.wt, P.half_dt);   // :184
+    integrate_attitude<kRaw>(e.qc, e.wc, P.half_dt);   // :181
+    integrate_attitude<kRaw>(e.qt, e.wt, P.half_dt);   // :184
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = canon(e.wc[i], tag);

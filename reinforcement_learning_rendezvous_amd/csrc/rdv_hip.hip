@@ -257,7 +257,7 @@ __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i,
 }
 
 // step one lane's env (or report a halted one); returns whether a transition was executed
-template <typename ST, bool kDiag, bool kGeneral = false>
+template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false>
 __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, int64_t i, bool active, Env& e, const float* a,
                                         StepResult& r) {
   r.done = 0; r.reason = 0; r.reward = 0.0f;
@@ -271,7 +271,7 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
       r.done = 1;
       if (kDiag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
     } else {
-      step_env<ST, !kDiag, kGeneral>(P, e, a, r, d);
+      step_env<ST, !kDiag, kGeneral, kRaw>(P, e, a, r, d);
       stepped = true;
       if (kDiag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);   // evaluator build only: keeps the training kernel short
     }
@@ -284,7 +284,8 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
 // The right shape when the chip is full (several waves per SIMD): no work is done twice.
 // kGeneral: general rigid bodies (rdv_set_rigid_body) — the attitude of both bodies is integrated with the reference's RK45
 // scheme instead of the closed form, and the target's rate is part of the state that is written back.
-template <typename ST, bool kDiag, bool kGeneral = false>
+// kRaw: the first step after rdv_set_state (quaternions that need not be normalised, see integrate_attitude).
+template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false>
 __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   load_actions(A.actions, wave_base, rows, lane, active, wl, a);
 
   StepResult r;
-  const bool stepped = advance<ST, kDiag, kGeneral>(A, P, i, active, e, a, r);
+  const bool stepped = advance<ST, kDiag, kGeneral, kRaw>(A, P, i, active, e, a, r);
   const bool fin = stepped && r.done;
   stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
   store_step_outputs<true>(A, i, active, fin, r, e);
@@ -637,6 +638,7 @@ struct RdvEnvBatch {
   int variant;       // RdvKernelVariant
   RdvRigidBody body; // rdv_set_rigid_body
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
+  bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
@@ -834,6 +836,7 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: call rdv_reset first (state is undefined until reset(), as in the reference)");
   if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_policy_act + rdv_step");
   DeviceGuard guard(h->device);
+  h->raw_state = false;   // the rollout kernel integrates injected (unnormalised) quaternions itself
   RolloutArgs A;
   A.ws = h->ws; A.stats = h->stats; A.obs = out->obs; A.actions = out->actions; A.reward = out->reward; A.done = out->done;
   A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.seed = h->seed;
@@ -864,6 +867,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   if (!h) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_create: host allocation failed");
   h->magic = kMagic; h->params = *params; derive_params(*params, h->dev);
   (void)rdv_rigid_body_default(&h->body); h->general = false; apply_rigid_body(h);
+  h->raw_state = false;
 
   h->n = n_envs; h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
@@ -1064,7 +1068,9 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
 #endif
   hipStream_t s = static_cast<hipStream_t>(stream);
   // general rigid bodies run on the fused layout only (their integrator is a per-lane adaptive loop: no fixed phase to split)
-  const bool split = !h->general && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
+  const bool raw = h->raw_state && !h->general;   // (the RK45 kernels integrate the quaternion as given, like the reference)
+  h->raw_state = false;
+  const bool split = !h->general && !raw && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
   const dim3 block(split ? kSplitBlock : kBlock);
   const dim3 grid = split ? dim3((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)) : grid_for(h->n);
 #define RDV_LAUNCH_STEP(KERNEL)                                                         \
@@ -1078,6 +1084,15 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
     }                                                                                   \
   } while (0)
   if (split) RDV_LAUNCH_STEP(step_kernel_split);
+  else if (raw) {
+    if (h->storage == RDV_STORAGE_F32) {
+      if (A.diag) hipLaunchKernelGGL((step_kernel<float, true, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+      else hipLaunchKernelGGL((step_kernel<float, false, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+    } else {
+      if (A.diag) hipLaunchKernelGGL((step_kernel<double, true, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+      else hipLaunchKernelGGL((step_kernel<double, false, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+    }
+  }
   else if (!h->general) RDV_LAUNCH_STEP(step_kernel);
   else if (h->storage == RDV_STORAGE_F32) {
     if (A.diag) hipLaunchKernelGGL((step_kernel<float, true, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
@@ -1104,6 +1119,7 @@ int rdv_set_state(rdv_handle h, const double* states, void* stream) {
   RDV_CHECK_HANDLE(h);
   if (!states) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_state: null states");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_state: call rdv_reset first (monte_carlo.py:106 resets before overwriting the state)");
+  h->raw_state = true;
   return access(h, ACC_SET_STATE, states, nullptr, nullptr, stream);
 }
 int rdv_get_state(rdv_handle h, double* out, void* stream) {

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #pragma unroll
       for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[slot * RDV_ACT_DIM + j] : 0.0f;
       StepResult r;
-      const bool stepped = advance<ST, false>(SA, P, i, active, e, a, r);
+      const bool stepped = advance<ST, false, false, true>(SA, P, i, active, e, a, r);   // kRaw: a rollout may start from an injected state
       const bool fin = stepped && r.done;
       if (active) {
         A.reward[(int64_t)t * n + i] = r.reward;

@@ -126,3 +126,61 @@ def test_nan_actions_end_the_episode_by_obs():
     assert np.isfinite(_np(o)).all()                      # the returned observations are those of the fresh episodes
     o2, _, _ = env.step(torch.from_numpy(counter_actions(1, 1, n)).cuda())
     np.testing.assert_allclose(_np(o2), orc.step(counter_actions(1, 1, n))["obs"], rtol=0, atol=2.4e-7)
+
+
+def test_adversarial_states_terminate_like_the_oracle():
+    """States no rollout produces, injected with set_state as monte_carlo.py:107-112 does: zero / unnormalised / NaN quaternions,
+    infinities, values beyond float32, denormals, a chaser exactly at the target.  The kernel must neither hang nor disagree with
+    the CPU restatement on what ends the episode (NaNs may propagate differently into numbers that are never compared)."""
+    n = 64
+    p = make_params()
+    base = np.zeros((n, 20))
+    base[:, 1] = -10.0; base[:, 6] = 1.0; base[:, 13] = 1.0
+    s = base.copy()
+    s[1, 6:10] = 0.0                                    # zero chaser quaternion: quat2mat divides by its norm (quaternions.py:57)
+    s[2, 13:17] = 0.0                                   # zero target quaternion
+    s[3, 6:10] = [3.0, -4.0, 12.0, 0.5]                 # unnormalised: renormalised everywhere it is used
+    s[4, 13:17] = [1e-160, 0.0, 0.0, 1e-160]            # denormal-range norm
+    s[5, 0] = np.nan
+    s[6, 7] = np.nan
+    s[7, 17] = np.inf
+    s[8, 0:3] = [1e30, -1e30, 1e30]
+    s[9, 3:6] = [1e38, 0.0, 0.0]                        # overflows float32 after one CW step
+    s[10, 0:3] = 0.0                                    # chaser at the target's centre: angle_between_vectors divides by |rc| = 0
+    s[11, 0:3] = [0.0, -2.0, 0.0]; s[11, 3:6] = 0.0     # exactly at the docking point, at rest
+    s[12, 10:13] = [50.0, -50.0, 50.0]                  # spinning far beyond the observation bound
+    s[13, 0:3] = [0.0, -1e-310, 0.0]                    # subnormal position
+    s[14, 6:10] = [np.inf, 0.0, 0.0, 0.0]
+    for storage in ("f64", "f32"):
+        env = _batch(n, params=p, storage=storage, on_done="halt", seed=0)
+        orc = oracle.OracleBatch(n, to_oracle_params(p), seed=0, on_done=oracle.ON_DONE_HALT,
+                                 storage=oracle.STORAGE_F32 if storage == "f32" else oracle.STORAGE_F64)
+        env.reset(); orc.reset()
+        env.set_state(torch.from_numpy(s)); orc.set_state(s)
+        for t in range(6):
+            a = counter_actions(77, t, n)
+            o, r, d = env.step(torch.from_numpy(a).cuda())
+            ref = orc.step(a)
+            np.testing.assert_array_equal(_np(d), ref["done"], err_msg=f"{storage} done, step {t}")
+            np.testing.assert_array_equal(_np(env.done_reason) & 7, ref["done_reason"] & 7, err_msg=f"{storage} reason, step {t}")
+            ok = np.isfinite(ref["obs"]).all(axis=1) & np.isfinite(_np(o)).all(axis=1)
+            np.testing.assert_allclose(_np(o)[ok], ref["obs"][ok], rtol=0, atol=2.4e-7, err_msg=f"{storage} obs, step {t}")
+            np.testing.assert_array_equal(np.isnan(_np(o)).any(axis=1), np.isnan(ref["obs"]).any(axis=1), err_msg=f"{storage} NaN rows, step {t}")
+        assert _np(d)[[1, 2, 5, 6, 7, 8, 12, 14]].all()          # the poisoned envs are done (and halted), nothing hung
+        env.close()
+
+
+def test_adversarial_states_match_the_reference_golden():
+    """The same fixture the oracle is pinned to (tests/test_oracle_golden.py::check_adversarial), through the HIP path."""
+    from test_oracle_golden import check_adversarial
+
+    def step_fn(state0, actions):
+        env = _batch(len(state0), storage="f64", on_done="halt", seed=0)
+        env.reset()
+        env.set_state(torch.from_numpy(state0))
+        o, r, d = env.step(torch.from_numpy(actions).cuda(), diag=True)
+        out = dict(obs=_np(o).copy(), reward=_np(r).astype(np.float64), done=_np(d).copy(), reason=_np(env.done_reason).copy(),
+                   state=_np(env.get_state()), diag=_np(env.diag).copy())
+        env.close()
+        return out
+    check_adversarial(step_fn, nan_pattern=False)
