@@ -62,6 +62,10 @@ class OracleEngine:
     def seed(self, seed):
         self._orc.seed(seed)
 
+    def set_reset_tape(self, tape):
+        self._orc.set_reset_tape(None if tape is None else np.asarray(tape.detach().cpu().numpy() if hasattr(tape, "detach") else tape,
+                                                                    dtype=np.float64))
+
     def set_params(self, params):
         self.params = params.copy()
         self._orc.params = to_oracle_params(params)

@@ -76,3 +76,34 @@ def test_reset_distribution_moments_on_device():
     e2.reset(); e3.reset()
     np.testing.assert_array_equal(e2.get_state().cpu().numpy(), first[:1024])
     assert not np.array_equal(e3.get_state().cpu().numpy(), first[:1024])
+
+
+def test_reference_callback_metrics_and_trajectory_records_on_the_hip_engine():
+    """eval_reference.npz — the UNMODIFIED CustomWandbCallback.evaluate_policy and save_new_trajectory.evaluate of the reference,
+    recorded by tests/golden/make_golden_eval.py — replayed from the same initial states through the HIP engine and the HIP actor.
+    (tests/test_host_logic.py replays the same fixture on the CPU oracle with the PyTorch actor.)"""
+    from helpers import load_golden
+    from reinforcement_learning_rendezvous_amd import evaluation as ev
+    from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+    from reinforcement_learning_rendezvous_amd.params import make_params
+    g = load_golden("eval_reference.npz")
+    pol = _policy().to("cuda:0")
+    env = RendezvousBatch(24, params=make_params(), device="cuda:0", storage="f64", on_done="halt")
+    env.set_reset_tape(torch.from_numpy(g["cb_tape"][None]))
+    summary, _ = ev.evaluate_policy_batch(pol, env)
+    ref = dict(zip([str(k) for k in g["cb_metric_names"]], g["cb_metrics"]))
+    for k in ("ep_len", "ep_success", "ep_collision_percentage", "ep_time_of_first_collision", "%_collided_episodes",
+              "%_successfull_episodes"):
+        assert summary[k] == pytest.approx(ref[k], rel=1e-12), k
+    for k in ("ep_rew", "ep_dist", "ep_delta_v", "ep_delta_w", "ep_min_pos_error", "ep_avg_att_error"):
+        assert summary[k] == pytest.approx(ref[k], rel=5e-5), k
+    env.close()
+    env = RendezvousBatch(3, params=make_params(), device="cuda:0", storage="f64", on_done="halt")
+    recs = ev.record_trajectories(pol, env, initial_states=np.stack([g[f"traj{j}_state0"] for j in range(3)]))
+    for j, rec in enumerate(recs):
+        for k in ("rc", "vc", "qc", "wc", "qt", "wt", "a", "rew", "errors", "t"):
+            want = g[f"traj{j}_{k}"]
+            assert rec[k].shape == want.shape, (j, k)
+            np.testing.assert_allclose(np.nan_to_num(rec[k]), np.nan_to_num(want), rtol=0, atol=5e-4, err_msg=f"{j} {k}")
+        assert rec["collisions"] == int(g[f"traj{j}_scalars"][1]) and rec["successes"] == int(g[f"traj{j}_scalars"][2])
+    env.close(); pol.close()

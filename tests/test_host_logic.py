@@ -335,3 +335,42 @@ def test_monte_carlo_replicas_bookkeeping_on_the_oracle_engine():
     s = mc.replica_summary(full, 96)
     assert s["replicas"] == 2 and s["trajectories"] == 192 and s["success_percent_std"] == 0.0
     assert s["success_percent_mean"] == pytest.approx(mc.summary(det)["success_percent"])
+
+
+def test_evaluation_metrics_reproduce_the_reference_callback():
+    """eval_reference.npz (tests/golden/make_golden_eval.py): the 12 means the UNMODIFIED CustomWandbCallback.evaluate_policy logged
+    over 24 episodes of the unmodified env with the shipped policy, replayed from the same initial states."""
+    from reinforcement_learning_rendezvous_amd import evaluation as ev
+    torch.set_num_threads(1)
+    g = load_golden("eval_reference.npz")
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    env = OracleEngine(24, make_params(), storage="f64", on_done="halt")
+    env.set_reset_tape(g["cb_tape"][None])
+    summary, per = ev.evaluate_policy_batch(pol, env)
+    ref = dict(zip([str(k) for k in g["cb_metric_names"]], g["cb_metrics"]))
+    assert list(summary) == list(ref)
+    for k in ("ep_len", "ep_success", "ep_collision_percentage", "ep_time_of_first_collision", "%_collided_episodes",
+              "%_successfull_episodes"):                       # step counts: exact
+        assert summary[k] == pytest.approx(ref[k], rel=1e-12), k
+    for k in ("ep_rew", "ep_dist", "ep_delta_v", "ep_delta_w", "ep_min_pos_error", "ep_avg_att_error"):
+        # the reference evaluated the policy with NumPy float32 GEMVs, this replay with torch GEMMs: last-bit action differences
+        assert summary[k] == pytest.approx(ref[k], rel=2e-5), k
+
+
+def test_trajectory_records_reproduce_the_reference_script():
+    """save_new_trajectory.evaluate (unmodified) on three episodes: every array of the record, sample for sample."""
+    from reinforcement_learning_rendezvous_amd import evaluation as ev
+    torch.set_num_threads(1)
+    g = load_golden("eval_reference.npz")
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    env = OracleEngine(3, make_params(), storage="f64", on_done="halt")
+    recs = ev.record_trajectories(pol, env, initial_states=np.stack([g[f"traj{j}_state0"] for j in range(3)]))
+    for j, rec in enumerate(recs):
+        for k in ("rc", "vc", "qc", "wc", "qt", "wt", "a", "rew", "errors", "t"):
+            want = g[f"traj{j}_{k}"]
+            assert rec[k].shape == want.shape, (j, k, rec[k].shape, want.shape)
+            np.testing.assert_array_equal(np.isnan(rec[k]), np.isnan(want), err_msg=f"{j} {k}")
+            np.testing.assert_allclose(np.nan_to_num(rec[k]), np.nan_to_num(want), rtol=0, atol=2e-4, err_msg=f"{j} {k}")
+        d_koz, collisions, successes = g[f"traj{j}_scalars"]
+        assert rec["d_koz"] == pytest.approx(d_koz, abs=1e-4)
+        assert rec["collisions"] == int(collisions) and rec["successes"] == int(successes)
