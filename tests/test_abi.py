@@ -137,3 +137,23 @@ def test_product_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, re.M), f
                 assert "librdv_oracle" not in text and "rdv_oracle.h" not in text, f
+
+
+def test_constructor_and_make_env_surface_reproduce_the_reference():
+    """params_reference.npz (tests/golden/make_golden_params.py): the attributes the UNMODIFIED make_env / RendezvousEnv.__init__
+    derive for 11 configurations (defaults, Monte Carlo, reward kwargs, scalar rc0 / wt0, KOZ, altitudes up to GEO, dt, ranges,
+    array arguments) — all 57 RdvParams fields."""
+    import json
+    from helpers import load_golden
+    g = load_golden("params_reference.npz")
+    assert [str(f) for f in g["fields"]] == [n for n, _ in EnvParams._fields_]
+    for note, want in zip(g["cases"], g["table"]):
+        c = json.loads(str(note))
+        kind = c.pop("kind")
+        if kind == "make_env":
+            p = params_from_config(reward_kwargs=c["reward_kwargs"], config=c["config"], stochastic=c["stochastic"])
+        else:
+            p = make_params(**{k: np.array(v, dtype=float) for k, v in c.items()})
+        got = np.concatenate([np.atleast_1d(np.asarray(p.to_dict()[n], dtype=np.float64)) for n, _ in EnvParams._fields_])
+        np.testing.assert_allclose(got, want, rtol=1e-15, atol=0, err_msg=str(note))
+        assert N.lib().rdv_params_validate(C.byref(p)) == 0
