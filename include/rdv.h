@@ -54,7 +54,10 @@ typedef enum RdvStorage {
 /* What a finished episode does (SB3 DummyVecEnv auto-resets; monte_carlo.py:128 stops at done). */
 typedef enum RdvOnDone {
   RDV_ON_DONE_RESET = 0,  /* in-kernel reset; obs returned is the first obs of the next episode */
-  RDV_ON_DONE_HALT = 1    /* env freezes: later steps leave it untouched and report done=1, reward=0 */
+  RDV_ON_DONE_HALT = 1,   /* env freezes: later steps leave it untouched and report done=1, reward=0 */
+  RDV_ON_DONE_CONTINUE = 2 /* nothing happens: the env keeps stepping, as the reference's env object does when its caller ignores
+                              `done` (the verification/ scripts propagate for hundreds of seconds past it); every such step
+                              reports done again and counts as a finished episode in the statistics */
 } RdvOnDone;
 
 /* Which step kernel rdv_step launches.  Both give the same results (same arithmetic); they differ in how the work of a

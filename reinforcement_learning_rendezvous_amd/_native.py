@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_PKG, "librdv_hip.so")
 CSRC = os.path.join(_PKG, "csrc")
 
 STORAGE_F32, STORAGE_F64 = 0, 1
-ON_DONE_RESET, ON_DONE_HALT = 0, 1
+ON_DONE_RESET, ON_DONE_HALT, ON_DONE_CONTINUE = 0, 1, 2
 VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT = 0, 1, 2
 OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM = 17, 6, 20, 8, 8
 

@@ -5,7 +5,8 @@ Tensor-native: actions come in and observations/rewards/dones go out as torch te
 for device memory and streams only.  The SB3-facing NumPy VecEnv lives in vec_env.py on top of this class.
 
 Reference semantics: RendezvousEnv.step()/reset() (rendezvous_env.py:160-270) for every env of the batch, with SB3
-DummyVecEnv auto-reset (``on_done="reset"``) or monte_carlo.py's stop-at-done (``on_done="halt"``).
+DummyVecEnv auto-reset (``on_done="reset"``), monte_carlo.py's stop-at-done (``on_done="halt"``), or the bare env object whose
+caller ignores ``done`` and keeps stepping (``on_done="continue"``, what the reference's verification/ scripts do).
 """
 import ctypes as C
 
@@ -16,7 +17,7 @@ from . import _native as N
 from .params import EnvParams, make_params
 
 _STORAGE = {"f32": N.STORAGE_F32, "f64": N.STORAGE_F64, N.STORAGE_F32: N.STORAGE_F32, N.STORAGE_F64: N.STORAGE_F64}
-_ON_DONE = {"reset": N.ON_DONE_RESET, "halt": N.ON_DONE_HALT}
+_ON_DONE = {"reset": N.ON_DONE_RESET, "halt": N.ON_DONE_HALT, "continue": N.ON_DONE_CONTINUE}
 _VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT}
 
 

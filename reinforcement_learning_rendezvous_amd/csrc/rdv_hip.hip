@@ -331,7 +331,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
       reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, row);
       observation(P, e, r.obs);
       did_reset = true;
-    } else {
+    } else if (A.on_done == RDV_ON_DONE_HALT) {
       e.flags |= FLAG_HALTED;
     }
   }
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
     store_step_outputs<true>(A, i, active, fin, r, e);
     RDV_STAMP(3);
-    if (fin && !resets) e.flags |= FLAG_HALTED;
+    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
     // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores.  If an env of this wave resets,
     // the rows stay in LDS: the service wave swaps in the reset observation and stores the block after the barrier.
 #pragma unroll
@@ -855,7 +855,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   if (!params || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: null params/out");
   if (n_envs <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: n_envs must be positive (got %lld)", (long long)n_envs);
   if (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: bad storage %d", storage);
-  if (on_done != RDV_ON_DONE_RESET && on_done != RDV_ON_DONE_HALT) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: bad on_done %d", on_done);
+  if (on_done != RDV_ON_DONE_RESET && on_done != RDV_ON_DONE_HALT && on_done != RDV_ON_DONE_CONTINUE) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_create: bad on_done %d", on_done);
   if (int rc = rdv_params_validate(params)) return rc;
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)

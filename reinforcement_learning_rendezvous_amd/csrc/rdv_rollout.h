@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
           reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, row);
           observation(P, e, r.obs);
           wt_dirty = true;
-        } else {
+        } else if (A.on_done == RDV_ON_DONE_HALT) {
           e.flags |= FLAG_HALTED;
         }
       }

@@ -19,7 +19,7 @@ class OracleEngine:
         self._orc = oracle.OracleBatch(
             self.num_envs, to_oracle_params(params),
             storage=oracle.STORAGE_F32 if storage == "f32" else oracle.STORAGE_F64,
-            on_done=oracle.ON_DONE_HALT if on_done == "halt" else oracle.ON_DONE_RESET,
+            on_done={"halt": oracle.ON_DONE_HALT, "continue": oracle.ON_DONE_NOTHING}.get(on_done, oracle.ON_DONE_RESET),
             seed=seed, env_id_offset=env_id_offset, n_threads=n_threads, numpy_legacy=numpy_legacy)
         self.obs = self.reward = self.done = None
         self.terminal_obs = self.episode_return = self.episode_length = self.done_reason = self.diag = None

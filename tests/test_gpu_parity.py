@@ -184,3 +184,57 @@ def test_errors_are_loud():
         _batch(0)
     with pytest.raises(AssertionError):
         _batch(4, koz_radius=1.5)                                 # reference assert :155
+
+
+def test_verification_script_scenarios_on_the_gpu():
+    """The known answers of the reference's verification/ scripts (tests/test_oracle_golden.py has them for
+    the oracle), through the HIP path with ``on_done="continue"`` — those scripts ignore `done` and keep stepping the env object."""
+    import oracle
+    from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+    from reinforcement_learning_rendezvous_amd.params import make_params
+    quiet = dict(rc0_range=0, vc0_range=0, qc0_range=0, wc0_range=0, qt0_range=0, wt0_range=0)
+    zero = torch.zeros((64, 6), device="cuda:0")
+    # KAT-1 verification/verify_cw.py:12-74: K zero-action steps == one closed-form CW propagation over K*dt
+    p = make_params(**quiet)
+    s = np.array([0.3, -9.0, 0.2, 0.01, -0.02, 0.005, 1, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0.0])
+    env = RendezvousBatch(64, params=p, device="cuda:0", storage="f64", on_done="continue")
+    env.reset(); env.set_state(torch.from_numpy(np.tile(s, (64, 1))))
+    n_done = 0
+    for _ in range(200):
+        _, _, d = env.step(zero)
+        n_done += int(d[0])
+    r, v = oracle.cw_solution(s[0:3], s[3:6], p.n, 200 * p.dt)
+    st = env.get_state().cpu().numpy()
+    np.testing.assert_allclose(st[:, 0:3], np.tile(r, (64, 1)), rtol=0, atol=1e-10)
+    np.testing.assert_allclose(st[:, 3:6], np.tile(v, (64, 1)), rtol=0, atol=1e-12)
+    assert n_done > 50 and float(env.get_aux()[0, 0]) == 200.0          # done was reported (t >= t_max = 120 s) and ignored
+    env.close()
+    # KAT-4 verification/verify_attitude_torque.py:34-60: action [0,0,0,0,0,0.5], dt = 0.5, 65 steps -> w_z = 0.195 rad/s
+    p = make_params(dt=0.5, **quiet)
+    env = RendezvousBatch(64, params=p, device="cuda:0", storage="f64", on_done="continue")
+    env.reset()
+    a = torch.zeros((64, 6), device="cuda:0"); a[:, 5] = 0.5
+    for _ in range(65):
+        env.step(a)
+    st = env.get_state().cpu().numpy()
+    assert st[0, 12] == pytest.approx(0.195, rel=1e-9) and np.abs(np.linalg.norm(st[:, 6:10], axis=1) - 1).max() < 1e-15
+    env.close()
+    # KAT-5 verification/verify_attitude_racket.py:34-45: the env's isotropic body -> rate constant over 760 s, |q| = 1
+    p = make_params(**quiet)
+    s = np.zeros(20); s[1] = -10; s[6] = 1; s[13] = 1; s[10:13] = np.radians([0, 5, 0.01])
+    env = RendezvousBatch(64, params=p, device="cuda:0", storage="f64", on_done="continue")
+    env.reset(); env.set_state(torch.from_numpy(np.tile(s, (64, 1))))
+    for _ in range(760):
+        env.step(zero)
+    st = env.get_state().cpu().numpy()
+    np.testing.assert_array_equal(st[:, 10:13], np.tile(s[10:13], (64, 1)))
+    assert np.abs(np.linalg.norm(st[:, 6:10], axis=1) - 1).max() < 1e-15
+    # ... and with a tri-axial body the same start does flip about the intermediate axis (the effect the script was written to show)
+    env.set_rigid_body(inertia=[10.0, 20.0, 30.0])
+    env.set_state(torch.from_numpy(np.tile(s, (64, 1))))
+    wy = []
+    for _ in range(760):
+        env.step(zero)
+        wy.append(float(env.get_state()[0, 11]))
+    assert min(wy) < -0.9 * s[11] and max(wy) > 0.9 * s[11]             # w_y changes sign: Dzhanibekov flips
+    env.close()
