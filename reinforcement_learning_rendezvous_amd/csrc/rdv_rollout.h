@@ -14,10 +14,11 @@
 //     at 65,536 envs, ~5 us are launch gaps and kernel entry/exit, and the state / observation round trips.
 // Phase A (actor waves): obs_t rows -> HBM; the actor of rdv_policy.h (bf16x3 MFMAs, register-resident), noise, clip -> LDS and HBM.
 // Phase B (env waves): transition, reward/done -> HBM, in-lane reset where an episode ended, obs_{t+1} -> LDS.
-// (Measured and dropped: preparing every env's next initial state in LDS while the env waves wait for the actor — the fp64 filler
-// work slows the actor waves of the same SIMD by as much as the in-lane reset costs; and drawing the noise before the layers in
-// every second actor wave, or a static priority for one of them, to shift the two actor waves of a SIMD against each other — no
-// effect: the fp32-input MFMA time adds to the vector work, rdv_policy.h.)
+// (Measured and dropped, all bit-identical in results: (a) preparing every env's next initial state in LDS while the env waves wait
+// for the actor — the vector pipe is the shared resource of both phases, so the fp64 filler work lengthens the actor phase by what
+// it takes off the env phase (13.3 -> 13.6 us per step); (b) actor waves 0-3 doubling as service waves during the env phase, as in
+// step_kernel_split — the reset code inside the actor loop pushes the kernel over its 168-VGPR budget (three waves per SIMD) and
+// the actor itself spills: 20.7 us per step; (c) shifting the two actor waves of a SIMD against each other or prioritising one.)
 #pragma once
 
 namespace rdv {
