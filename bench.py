@@ -222,6 +222,32 @@ def main():
         if gather_ms is not None:
             out["rccl_gather_to_rank0_ms"] = gather_ms
 
+    # ---- informational: the same open-loop workload as K steps per persistent launch (rdv_step_many) — NOT the headline shape
+    if rank == 0 and world == 1:
+        try:
+            k_many = 64
+            tape = torch.stack([ring[t % RING] for t in range(k_many)]).contiguous()
+            env.reset()
+            bufs = env.step_many(tape)
+            for _ in range(3):
+                env.step_many(tape, out=bufs)
+            torch.cuda.synchronize()
+            m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 32
+            m0.record()
+            for _ in range(reps):
+                env.step_many(tape, out=bufs)
+            m1.record()
+            torch.cuda.synchronize()
+            us = m0.elapsed_time(m1) * 1e3 / (reps * k_many)
+            out["open_loop_multi_step"] = {"value": n / (us * 1e-6), "unit": "env steps/s", "us_per_step": us, "steps_per_launch": k_many,
+                                           "kernel": "rdv::step_many_kernel<" + ("float" if args.storage == "f32" else "double") + ">",
+                                           "note": "one persistent launch per 64 steps of an action tape resident in HBM (state in registers); "
+                                                   "`value` above is one launch per timestep, as the metric is defined"}
+            del bufs, tape
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            out["open_loop_multi_step"] = {"error": repr(exc)}
+
     # ---- informational: MLP-policy rollout (config 3), N=1 only
     if rank == 0 and world == 1 and not args.no_policy:
         from reinforcement_learning_rendezvous_amd.policy import MlpPolicy

@@ -116,6 +116,23 @@ class RendezvousBatch:
         N.check(self._lib.rdv_step(self._h, actions.data_ptr(), C.byref(out), self._stream()))
         return self.obs, self.reward, self.done
 
+    def step_many(self, actions, out=None):
+        """``step`` for every row of an OPEN-LOOP action tape ``actions`` [K,N,6] in ONE kernel launch (state in registers, no
+        launch boundaries).  Returns a dict ``obs`` [K,N,17], ``reward`` [K,N], ``done`` [K,N] (uint8), ``done_reason`` [K,N];
+        pass it back as ``out`` to reuse the buffers.  Same results as calling ``step`` K times."""
+        K, n, dev = int(actions.shape[0]), self.num_envs, self.device
+        self._check_tensor(actions, (K, n, N.ACT_DIM), torch.float32, "actions")
+        if out is None or out["obs"].shape[0] != K:
+            out = dict(obs=torch.empty((K, n, N.OBS_DIM), dtype=torch.float32, device=dev),
+                       reward=torch.empty((K, n), dtype=torch.float32, device=dev),
+                       done=torch.empty((K, n), dtype=torch.uint8, device=dev),
+                       done_reason=torch.empty((K, n), dtype=torch.uint8, device=dev))
+        so = N.StepOut(out["obs"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(), None, None, None,
+                       out["done_reason"].data_ptr(), None)
+        N.check(self._lib.rdv_step_many(self._h, actions.data_ptr(), K, C.byref(so), self._stream()))
+        self.obs.copy_(out["obs"][K - 1]); self.reward.copy_(out["reward"][K - 1]); self.done.copy_(out["done"][K - 1])
+        return out
+
     def rollout(self, policy, n_steps, deterministic=False, out=None):
         """``n_steps`` of the closed loop  a_t ~ policy(obs_t); obs_{t+1}, r_t, done_t = step(clip(a_t))  in ONE kernel launch
         (the inner loop of SB3's ``collect_rollouts``, main.py:114): the env state stays in registers, observations and

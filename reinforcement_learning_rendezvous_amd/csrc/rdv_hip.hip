@@ -516,6 +516,7 @@ __global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void*
 
 }  // namespace rdv
 #include "rdv_rollout.h"
+#include "rdv_step_many.h"
 namespace rdv {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -892,6 +893,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   // the rollout kernel uses 78 KiB of dynamic LDS (above the 64 KiB default limit); raised here, outside any stream capture
   if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes);
   if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes);
+  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<double>());
   if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset of the workspace failed: %s", hipGetErrorString(err)); }
   h->host_slots.resize((size_t)(n_waves(n_envs) * kStatWords));
   *out = h;
@@ -1102,6 +1104,32 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
     else hipLaunchKernelGGL((step_kernel<double, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
   }
 #undef RDV_LAUNCH_STEP
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
+}
+
+int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const RdvStepOut* out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (n_steps <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: n_steps must be positive (got %d)", n_steps);
+  if (!actions || !out || !out->obs || !out->reward || !out->done)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions, obs, reward and done are required");
+  if (out->terminal_obs || out->episode_return || out->episode_length || out->diag)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: terminal_obs, episode_return, episode_length and diag are outputs of rdv_step only");
+  if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: call rdv_reset first (state is undefined until reset(), as in the reference)");
+  if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_step");
+  if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions and obs must be 16-byte aligned");
+  if ((h->n & 3) != 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: n_envs must be a multiple of 4 (rows of [K,N,17] / [K,N,6] start 16-byte aligned)");
+  DeviceGuard guard(h->device);
+  h->raw_state = false;   // the kernel integrates injected (unnormalised) quaternions itself
+  StepManyArgs A;
+  A.ws = h->ws; A.stats = h->stats; A.actions = actions; A.obs = out->obs; A.reward = out->reward; A.done = out->done;
+  A.done_reason = out->done_reason; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
+  A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps;
+  const dim3 grid((unsigned)((h->n + kManyEnvs - 1) / kManyEnvs)), block(kManyBlock);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(step_many_kernel<float>, grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
+  else hipLaunchKernelGGL(step_many_kernel<double>, grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }

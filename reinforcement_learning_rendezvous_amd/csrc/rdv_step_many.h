@@ -1,0 +1,164 @@
+// rdv_step_many.h — K env steps in ONE persistent launch for an OPEN-LOOP action tape actions[K][N][6] (random-action
+// workloads, replaying recorded actions): rdv_step called K times, without the launch boundaries and without the state's round
+// trips through HBM.  Not the closed loop (that is rdv_rollout, with the actor in the loop) and not the shape the headline
+// metric is quoted on (one launch per timestep, rdv_step); it shows what those boundaries cost: ~7.8 us per step -> ~4 us.
+//
+// Included by rdv_hip.hip after the step helpers.  Same arithmetic as rdv_step (the tests require bit-identical outputs, state
+// and statistics).  A 512-thread workgroup owns 256 envs for all K steps, split-role as step_kernel_split:
+//   - waves 0-3 ("env waves", 64 envs each) keep the state in registers and do the transition; the actions of step t+1 are
+//     fetched into registers while step t computes;
+//   - waves 4-7 ("service waves", on the same SIMDs) compute every env's next initial state + observation beside each step and
+//     hand it over through LDS where an episode ended (two workgroup barriers per step), so the reset is never on the env waves'
+//     critical path.
+#pragma once
+
+namespace rdv {
+
+constexpr int kManyEnvs = 256;
+constexpr int kManyEnvWaves = kManyEnvs / kWave;   // 4
+constexpr int kManyBlock = 2 * kManyEnvs;          // 512 threads: 4 env waves + 4 service waves
+// dynamic LDS: observation rows [256][17] | action rows [256][6] | finished flags [256] | 4 statistics slots | next states [7][256] x (4 ST)
+constexpr int kManyLdsFixed = (kManyEnvs * RDV_OBS_DIM + kManyEnvs * RDV_ACT_DIM + kManyEnvs) * 4 + kManyEnvWaves * kStatWords * 8;
+template <typename ST> constexpr int many_lds_bytes() { return kManyLdsFixed + kChunks * kManyEnvs * 4 * (int)sizeof(ST); }   // 53,760 / 82,432 B
+
+struct StepManyArgs {
+  void* ws;                 // chunk arrays (state in, state out)
+  uint64_t* stats;          // [n_waves][16]
+  const float* actions;     // [K][N][6]
+  float* obs;               // [K][N][17]  observation returned by step k (after an auto-reset: the reset observation)
+  float* reward;            // [K][N]
+  uint8_t* done;            // [K][N]
+  uint8_t* done_reason;     // nullable [K][N]
+  const double* tape;       // nullable [depth][N][20]
+  int64_t n;
+  uint64_t seed;
+  uint64_t env_id_offset;
+  int32_t tape_depth;
+  int32_t on_done;
+  int32_t n_steps;
+};
+
+template <typename ST>
+__global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* __restrict__ Pp, const StepManyArgs A) {
+  using V = typename Vec4<ST>::type;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* obs_rows = lds;                                                           // [256][17]
+  float* act_rows = obs_rows + kManyEnvs * RDV_OBS_DIM;                            // [256][6]
+  uint32_t* fin_flag = reinterpret_cast<uint32_t*>(act_rows + kManyEnvs * RDV_ACT_DIM);   // [256]
+  uint64_t* stat_lds = reinterpret_cast<uint64_t*>(fin_flag + kManyEnvs);          // [4][16]
+  V* nxt = reinterpret_cast<V*>(stat_lds + kManyEnvWaves * kStatWords);            // [7][256]
+  const DevParams& P = *Pp;   // scalar loads (see step_kernel)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x >> 6;
+  const bool env_role = wv < kManyEnvWaves;
+  const int slot = (wv & (kManyEnvWaves - 1)) * kWave + lane;    // both roles: the env this lane is responsible for
+  const int64_t n = A.n;
+  const int64_t i = (int64_t)blockIdx.x * kManyEnvs + slot;
+  const int64_t wave_base = i - lane;
+  const bool active = i < n;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  const int K = A.n_steps;
+  const bool resets = A.on_done == RDV_ON_DONE_RESET;
+  V* ws = reinterpret_cast<V*>(A.ws);
+
+  if (env_role) {
+    // ------------------------------------------------------------------ env waves
+    __builtin_amdgcn_s_setprio(2);
+    float* my_obs = obs_rows + (slot - lane) * RDV_OBS_DIM;
+    float* my_act = act_rows + (slot - lane) * RDV_ACT_DIM;
+    uint64_t* my_stats = stat_lds + wv * kStatWords;
+    if (lane < kStatWords) my_stats[lane] = 0ull;
+    Env e;
+    bool wt_dirty = false;
+    if (active) load_env<ST>(ws, n, i, e);
+    StepArgs SA;
+    SA.diag = nullptr;
+    // the wave's action rows [64][6] of one step are 384 contiguous floats: 3 x float2 per lane
+    auto fetch = [&](int k, float2 (&pre)[3]) {
+      const float* src = A.actions + ((int64_t)k * n + wave_base) * RDV_ACT_DIM;
+      const int64_t valid = rows * RDV_ACT_DIM;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        const int idx = q * 128 + lane * 2;
+        pre[q] = make_float2(0.0f, 0.0f);
+        if (idx + 1 < valid) pre[q] = *reinterpret_cast<const float2*>(src + idx);
+        else if (idx < valid) pre[q].x = src[idx];
+      }
+    };
+    float2 pre[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
+    if (rows > 0) fetch(0, pre);
+    for (int k = 0; k < K; ++k) {
+      // actions of this step: registers -> LDS rows -> own row; then request the next step's while this one computes
+#pragma unroll
+      for (int q = 0; q < 3; ++q) *reinterpret_cast<float2*>(my_act + q * 128 + lane * 2) = pre[q];
+      wave_lds_fence();
+      float a[RDV_ACT_DIM];
+#pragma unroll
+      for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? my_act[lane * RDV_ACT_DIM + j] : 0.0f;
+      if (rows > 0 && k + 1 < K) fetch(k + 1, pre);
+      StepResult r;
+      const bool stepped = advance<ST, false, false, true>(SA, P, i, active, e, a, r);   // kRaw: the tape may start from an injected state
+      const bool fin = stepped && r.done;
+      if (active) {
+        const int64_t o = (int64_t)k * n + i;
+        A.reward[o] = r.reward;
+        A.done[o] = (uint8_t)r.done;
+        if (A.done_reason)
+          A.done_reason[o] = (uint8_t)(r.reason | ((fin && (e.flags & FLAG_COLLIDED)) ? 16 : 0) | ((fin && (e.flags >> SUCCESS_SHIFT) != 0u) ? 32 : 0));
+      }
+      stats_update(my_stats, lane < 12 ? my_stats[lane] : 0ull, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+      if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+      fin_flag[slot] = (fin && resets) ? 1u : 0u;
+#pragma unroll
+      for (int j = 0; j < RDV_OBS_DIM; ++j) my_obs[lane * RDV_OBS_DIM + j] = r.obs[j];
+      __syncthreads();   // the service waves see the finished-episode flags and may replace rows / hand states over
+      __syncthreads();   // ... done
+      if (fin && resets) {
+        load_env<ST>(nxt, kManyEnvs, slot, e);
+        wt_dirty = true;
+      }
+      store_obs_rows(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs);
+      wave_lds_fence();   // the rows are rewritten by the next step
+    }
+    if (active) store_env<ST>(ws, n, i, e, wt_dirty);
+    if (rows > 0 && lane < 12) {   // this wave's statistics slot in HBM += the launch's (counters as integers, sums as fp64)
+      uint64_t* slot_stats = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
+      const uint64_t pre_s = slot_stats[lane], add = my_stats[lane];
+      const uint64_t as_int = pre_s + add;
+      const uint64_t as_real = (uint64_t)__double_as_longlong(__longlong_as_double((long long)pre_s) + __longlong_as_double((long long)add));
+      slot_stats[lane] = lane <= ST_SUM_LEN ? as_int : as_real;
+    }
+  } else {
+    // ------------------------------------------------------------------ service waves
+    const bool s_active = active && resets;
+    uint32_t episode = 0;
+    if (s_active) episode = s2u(ws[5 * n + i].w);
+    V packed[kChunks];
+    float robs[RDV_OBS_DIM];
+    bool have = false;   // the prepared state depends only on (seed, env id, episode): it stays valid until it is used
+    for (int k = 0; k < K; ++k) {
+      if (s_active && !have) {
+        Env ne;
+        ne.episode = episode;
+        const double* row = nullptr;
+        if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
+        reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+        reset_aux<ST>(P, ne);
+        observation(P, ne, robs);
+        pack_env<ST>(ne, packed);
+        have = true;
+      }
+      __syncthreads();   // the transition of step k is done
+      if (s_active && fin_flag[slot] != 0u) {
+        have = false;
+        store_chunks<ST>(nxt, kManyEnvs, slot, packed, true);
+#pragma unroll
+        for (int j = 0; j < RDV_OBS_DIM; ++j) obs_rows[slot * RDV_OBS_DIM + j] = robs[j];   // SB3: the first obs of the next episode
+        episode += 1u;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace rdv
