@@ -18,7 +18,10 @@
 // for the actor — the vector pipe is the shared resource of both phases, so the fp64 filler work lengthens the actor phase by what
 // it takes off the env phase (13.3 -> 13.6 us per step); (b) actor waves 0-3 doubling as service waves during the env phase, as in
 // step_kernel_split — the reset code inside the actor loop pushes the kernel over its 168-VGPR budget (three waves per SIMD) and
-// the actor itself spills: 20.7 us per step; (c) shifting the two actor waves of a SIMD against each other or prioritising one.)
+// the actor itself spills: 20.7 us per step; (b') dedicated service waves as in rdv_step_many.h, with four actor waves of two 32-env
+// tiles each to stay at three waves per SIMD — the env phase drops to 4.5 us but a lone actor wave per SIMD no longer overlaps its
+// MFMAs with another wave's vector work and the actor phase grows to 8.4 us: 12.9 us per step with float32 state, 11.8 (from 11.5)
+// with float64; (c) shifting the two actor waves of a SIMD against each other or prioritising one.)
 #pragma once
 
 namespace rdv {
