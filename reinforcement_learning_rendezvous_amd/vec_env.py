@@ -227,6 +227,43 @@ class RendezvousVecEnv(_VecEnvBase):
             return [o[i].copy() for i in idx]
         raise AttributeError(f"RendezvousVecEnv does not implement env_method('{method_name}')")
 
+    # ------------------------------------------------------------------------------- tensor-native fast path (no host copies)
+    def step_tensor(self, actions):
+        """``step`` with device tensors in and out: actions [N,6] float32 on the batch's device -> (obs [N,17], reward [N], done [N]);
+        the buffers are overwritten by the next step.  ``batch.terminal_obs`` / ``episode_return`` / ``episode_length`` /
+        ``done_reason`` hold what ``infos`` would."""
+        return self.batch.step(actions)
+
+    # batched forms of the scalar helper methods of the reference env, on the current state (tensors on the batch's device)
+    def get_errors(self):
+        """rendezvous_env.py:451-468 for every env: [N,4] = position [m], velocity [m/s], attitude [rad], rotation rate [rad/s]."""
+        return self.batch.diagnose()[:, 0:4]
+
+    def get_attitude_error(self):
+        return self.batch.diagnose()[:, 2]                      # :424-434
+
+    def get_pos_error(self):
+        return self.batch.diagnose()[:, 0]                      # :443-449 with the goal position of :436-441
+
+    def check_collision(self):
+        return self.batch.diagnose()[:, 4] > 0                  # :388-404
+
+    def check_success(self):
+        return self.batch.diagnose()[:, 5].to(torch.int64)      # :406-422 (0 / 1)
+
+    def dist_from_koz(self):
+        return self.batch.diagnose()[:, 6]                      # :510-537
+
+    def get_observation(self):
+        return self.batch.observe()                             # :294-311
+
+    def set_state(self, states):
+        """Overwrite rc, vc, qc, wc, qt, wt ([N,20], CSV column order) as monte_carlo.py:107-112 does."""
+        self.batch.set_state(torch.as_tensor(states))
+
+    def get_state(self):
+        return self.batch.get_state()
+
     def env_is_wrapped(self, wrapper_class, indices=None):
         # no Monitor object exists, but its episode statistics are reported in infos[i]["episode"]
         return [False for _ in self._indices(indices)]

@@ -374,3 +374,32 @@ def test_trajectory_records_reproduce_the_reference_script():
         d_koz, collisions, successes = g[f"traj{j}_scalars"]
         assert rec["d_koz"] == pytest.approx(d_koz, abs=1e-4)
         assert rec["collisions"] == int(collisions) and rec["successes"] == int(successes)
+
+
+def test_vecenv_tensor_fast_path_and_batched_helpers():
+    """step_tensor and the batched forms of get_errors / check_collision / check_success / dist_from_koz /
+    set_state / get_state, against the per-env answers of env_method on the same engine."""
+    vec = _vec(12)
+    vec.reset()
+    s = vec.get_state().clone()
+    s[3, 0:3] = torch.tensor([3.0, 1.0, 0.5]); s[4, 0:3] = torch.tensor([0.0, -2.0, 0.0])     # inside the KOZ / at the docking point
+    vec.set_state(s)
+    assert torch.equal(vec.get_state(), s)
+    err, coll, succ, dk = vec.get_errors(), vec.check_collision(), vec.check_success(), vec.dist_from_koz()
+    assert err.shape == (12, 4) and coll.dtype == torch.bool and succ.dtype == torch.int64 and dk.shape == (12,)
+    assert bool(coll[3]) and not bool(coll[0]) and float(dk[3]) < 0 < float(dk[0])
+    per_env = vec.env_method("get_errors")
+    np.testing.assert_array_equal(err.numpy(), np.stack(per_env))
+    assert [bool(c) for c in coll] == vec.env_method("check_collision")
+    assert [int(c) for c in succ] == vec.env_method("check_success")
+    np.testing.assert_array_equal(vec.get_attitude_error().numpy(), err[:, 2].numpy())
+    np.testing.assert_array_equal(vec.get_pos_error().numpy(), err[:, 0].numpy())
+    np.testing.assert_array_equal(vec.get_observation().numpy(), np.stack(vec.env_method("get_observation")))
+    a = torch.from_numpy(counter_actions(1, 0, 12))
+    obs, rew, done = vec.step_tensor(a)
+    assert obs.shape == (12, 17) and rew.shape == (12,) and done.shape == (12,)
+    twin = _vec(12)
+    twin.reset(); twin.batch.set_state(s)
+    o2, r2, d2, _ = twin.step(a.numpy())
+    np.testing.assert_array_equal(obs.numpy(), o2); np.testing.assert_array_equal(rew.numpy(), r2)
+    np.testing.assert_array_equal(done.numpy().astype(bool), d2)
