@@ -229,6 +229,14 @@ int rdv_get_state(rdv_handle h, double* states_out, void* stream);
 /* aux_out [N,8] fp64: t, bubble_radius, collided, success, total_delta_v, total_delta_w, episode_return, episode_index */
 int rdv_get_aux(rdv_handle h, double* aux_out, void* stream);
 
+/* Snapshot / restore of the whole batch — state, bookkeeping (t, bubble, delta-v totals, episode return), flags (collided,
+ * halted, success count), episode counters (the reset RNG position) and the episode statistics — e.g. to resume an interrupted
+ * evaluation or to branch rollouts from a common state.  `dst` / `src`: device buffers of rdv_snapshot_bytes(h) bytes, valid for
+ * handles of the same n_envs and storage.  Parameters, seed and rigid bodies are not part of it. */
+int64_t rdv_snapshot_bytes(rdv_handle h);
+int rdv_snapshot(rdv_handle h, void* dst, void* stream);
+int rdv_restore(rdv_handle h, const void* src, void* stream);
+
 /* get_observation() (:294) and the evaluator helpers (:388-468, :510) on the current state. */
 int rdv_observe(rdv_handle h, float* obs_out, void* stream);
 int rdv_diagnose(rdv_handle h, double* diag_out, void* stream);

@@ -25,7 +25,7 @@ ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVI
 SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
            "rdv_set_kernel_variant", "rdv_rigid_body_default", "rdv_set_rigid_body", "rdv_get_rigid_body",
-           "rdv_reset", "rdv_step", "rdv_step_many", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_observe", "rdv_diagnose",
+           "rdv_reset", "rdv_step", "rdv_step_many", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_snapshot_bytes", "rdv_snapshot", "rdv_restore", "rdv_observe", "rdv_diagnose",
            "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act", "rdv_critic_create", "rdv_policy_value", "rdv_rollout"]
 
 
@@ -119,6 +119,9 @@ def lib():
         "rdv_set_state": (C.c_int, [vp, vp, vp]),
         "rdv_get_state": (C.c_int, [vp, vp, vp]),
         "rdv_get_aux": (C.c_int, [vp, vp, vp]),
+        "rdv_snapshot_bytes": (i64, [vp]),
+        "rdv_snapshot": (C.c_int, [vp, vp, vp]),
+        "rdv_restore": (C.c_int, [vp, vp, vp]),
         "rdv_observe": (C.c_int, [vp, vp, vp]),
         "rdv_diagnose": (C.c_int, [vp, vp, vp]),
         "rdv_get_stats": (C.c_int, [vp, C.POINTER(Stats), C.c_int, vp]),

@@ -183,6 +183,21 @@ class RendezvousBatch:
         """[N,8]: get_errors() x4 (:451), check_collision() (:388), check_success() (:406), dist_from_koz() (:510), collided"""
         return self._fetch(self._lib.rdv_diagnose, N.DIAG_DIM, torch.float64)
 
+    def snapshot(self, out=None):
+        """The whole batch (state, bookkeeping, flags, episode counters, statistics) as one uint8 tensor on the device."""
+        nbytes = int(self._lib.rdv_snapshot_bytes(self._h))
+        if out is None:
+            out = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+        N.check(self._lib.rdv_snapshot(self._h, out.data_ptr(), self._stream()))
+        return out
+
+    def restore(self, snap):
+        """Back to a ``snapshot()`` (of a batch with the same number of envs and storage); the observation buffer follows."""
+        if snap.numel() != int(self._lib.rdv_snapshot_bytes(self._h)) or snap.dtype != torch.uint8 or snap.device != self.device:
+            raise ValueError("restore: not a snapshot of a batch of this size / storage on this device")
+        N.check(self._lib.rdv_restore(self._h, snap.contiguous().data_ptr(), self._stream()))
+        self.obs.copy_(self.observe())
+
     def get_stats(self, reset=False):
         st = N.Stats()
         N.check(self._lib.rdv_get_stats(self._h, C.byref(st), int(bool(reset)), self._stream()))

@@ -1155,6 +1155,30 @@ int rdv_get_state(rdv_handle h, double* out, void* stream) {
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_state: null output");
   return access(h, ACC_GET_STATE, nullptr, out, nullptr, stream);
 }
+// ---- snapshot / restore of the whole batch (state, bookkeeping, flags, episode counters, statistics): the chunk arrays and the
+// statistics slots are one contiguous region at the start of the workspace
+int64_t rdv_snapshot_bytes(rdv_handle h) {
+  if (!h || h->magic != kMagic) return -1;
+  return chunk_bytes(h->n, h->storage) + stats_bytes(h->n);
+}
+int rdv_snapshot(rdv_handle h, void* dst, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!dst) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_snapshot: null destination");
+  if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_snapshot: nothing to save before the first rdv_reset");
+  DeviceGuard guard(h->device);
+  RDV_HIP(hipMemcpyAsync(dst, h->ws, (size_t)rdv_snapshot_bytes(h), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  return RDV_OK;
+}
+int rdv_restore(rdv_handle h, const void* src, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!src) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: null source");
+  DeviceGuard guard(h->device);
+  RDV_HIP(hipMemcpyAsync(h->ws, src, (size_t)rdv_snapshot_bytes(h), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  h->fresh = false;
+  h->raw_state = true;   // the snapshot may have been taken right after rdv_set_state
+  return RDV_OK;
+}
+
 int rdv_get_aux(rdv_handle h, double* out, void* stream) {
   RDV_CHECK_HANDLE(h);
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_aux: null output");
