@@ -136,8 +136,10 @@ class RendezvousVecEnv(_VecEnvBase):
                 for j in range(len(idx_list)):
                     code = codes[j]
                     dist = float(np.linalg.norm(t_obs[j][0:3]) * b.params.max_axial_distance)
+                    t_end = round(ep_l[j] * b.params.dt, 3)             # :193; the default dt = 1 is an int there: "21", not "21.0"
+                    t_end = int(t_end) if float(b.params.dt).is_integer() else t_end
                     print("Episode end | r = " + str(round(dist, 2)).rjust(5) + " | t = " +
-                          str(round(ep_l[j] * b.params.dt, 3)).rjust(4) + " | " + _END_REASONS[code & 7].center(8) +
+                          str(t_end).rjust(4) + " | " + _END_REASONS[code & 7].center(8) +
                           " | " + ("Collided" if code & 16 else " "))
             self._dirty = idx_list
         return obs_h, rew_h, done_h, self._infos
