@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RDV_ABI_VERSION 1
+#define RDV_ABI_VERSION 2
 #define RDV_OBS_DIM 17    /* rendezvous_env.py:133-137 */
 #define RDV_ACT_DIM 6     /* rendezvous_env.py:140-144 */
 #define RDV_STATE_DIM 20  /* rc3 vc3 qc4 wc3 qt4 wt3, the column order of results/data_monte_carlo_initial_conditions.csv */
@@ -60,12 +60,15 @@ typedef enum RdvOnDone {
                               reports done again and counts as a finished episode in the statistics */
 } RdvOnDone;
 
-/* Which step kernel rdv_step launches.  Both give the same results (same arithmetic); they differ in how the work of a
- * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 98304) and FUSED above. */
+/* Which step kernel rdv_step launches.  All give the same results (same arithmetic); they differ in how the work of a
+ * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 98304) and FUSED above.
+ * FUSED and SPLIT take an env's next initial state from its prepared slot (a copy) and refill the slot once per episode. */
 typedef enum RdvKernelVariant {
   RDV_VARIANT_AUTO = 0,
-  RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs, resets run divergently in-lane */
-  RDV_VARIANT_SPLIT = 2   /* step waves + service waves that precompute every env's next initial state beside them */
+  RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs; one wave per 512 envs refills the slots that were used */
+  RDV_VARIANT_SPLIT = 2,  /* step waves + service waves that refill the slots of the previous launch beside them, by part */
+  RDV_VARIANT_INLANE = 3  /* round 1's layout: resets computed divergently in the lane whose episode ended (the kernel of the
+                             evaluator-diagnostics / rigid-body / first-step-after-set_state configurations; a reference for the others) */
 } RdvKernelVariant;
 
 /*
@@ -152,7 +155,8 @@ int rdv_params_default(RdvParams* out_host);
 /* The asserts of the reference ctor (:148-156) + positivity checks. Host-only. */
 int rdv_params_validate(const RdvParams* params_host);
 
-/* Bytes of device memory one batch needs (persistent SoA state + stats). Host-only. */
+/* Bytes of device memory one batch needs (persistent SoA state + stats + parameter block + acos table + the prepared
+ * next-episode state of every env: 7 chunks, its observation and a tag). Host-only. */
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage);
 
 /*
@@ -165,8 +169,10 @@ int rdv_create(const RdvParams* params_host, int64_t n_envs, int device, int sto
                uint64_t seed, uint64_t env_id_offset, void* workspace, rdv_handle* out);
 int rdv_destroy(rdv_handle h);
 
-/* Replace parameters (reward coefficients, ranges, limits ...) between steps.  n/dt changes re-derive the CW matrix. */
-int rdv_set_params(rdv_handle h, const RdvParams* params_host);
+/* Replace parameters (reward coefficients, ranges, limits ...) between steps.  n/dt changes re-derive the CW matrix.
+ * The new block is written by a kernel enqueued on `stream`: ordered like a step (launches already on that stream see the old
+ * values, later ones the new), legal inside a stream capture, no host synchronisation. */
+int rdv_set_params(rdv_handle h, const RdvParams* params_host, void* stream);
 int rdv_get_params(rdv_handle h, RdvParams* out_host);
 /* Re-key the reset RNG (VecEnv.seed()).  Episode counters restart at 0. */
 int rdv_seed(rdv_handle h, uint64_t seed);
@@ -207,7 +213,7 @@ typedef struct RdvRigidBody {
 } RdvRigidBody;
 
 int rdv_rigid_body_default(RdvRigidBody* out_host);                    /* the reference constructor's values, AUTO */
-int rdv_set_rigid_body(rdv_handle h, const RdvRigidBody* body_host);   /* synchronises the device, like rdv_set_params */
+int rdv_set_rigid_body(rdv_handle h, const RdvRigidBody* body_host, void* stream);   /* ordered on `stream`, like rdv_set_params */
 int rdv_get_rigid_body(rdv_handle h, RdvRigidBody* out_host);
 
 /* RendezvousEnv.reset() (:223-270) for every env, or for envs with mask[i] != 0.  obs_out [N,17] nullable. */
@@ -232,10 +238,12 @@ int rdv_get_aux(rdv_handle h, double* aux_out, void* stream);
 /* Snapshot / restore of the whole batch — state, bookkeeping (t, bubble, delta-v totals, episode return), flags (collided,
  * halted, success count), episode counters (the reset RNG position) and the episode statistics — e.g. to resume an interrupted
  * evaluation or to branch rollouts from a common state.  `dst` / `src`: device buffers of rdv_snapshot_bytes(h) bytes, valid for
- * handles of the same n_envs and storage.  Parameters, seed and rigid bodies are not part of it. */
+ * handles of the same n_envs and storage: a snapshot starts with a 64-byte header (magic, version, n_envs, storage, payload bytes)
+ * that rdv_restore reads back and checks against the handle and against `src_bytes`, the size of the caller's buffer, before
+ * anything is overwritten (this synchronises `stream`).  Parameters, seed and rigid bodies are not part of it. */
 int64_t rdv_snapshot_bytes(rdv_handle h);
 int rdv_snapshot(rdv_handle h, void* dst, void* stream);
-int rdv_restore(rdv_handle h, const void* src, void* stream);
+int rdv_restore(rdv_handle h, const void* src, int64_t src_bytes, void* stream);
 
 /* get_observation() (:294) and the evaluator helpers (:388-468, :510) on the current state. */
 int rdv_observe(rdv_handle h, float* obs_out, void* stream);

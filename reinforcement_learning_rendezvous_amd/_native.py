@@ -15,7 +15,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 STORAGE_F32, STORAGE_F64 = 0, 1
 ON_DONE_RESET, ON_DONE_HALT, ON_DONE_CONTINUE = 0, 1, 2
-VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT = 0, 1, 2
+VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT, VARIANT_INLANE = 0, 1, 2, 3
 OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM = 17, 6, 20, 8, 8
 
 ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVICE", -3: "RDV_ERR_HIP",
@@ -73,11 +73,8 @@ class RigidBody(C.Structure):
 
 
 def build(force=False, quiet=True):
-    """Compile csrc/rdv_hip.hip for gfx950 into librdv_hip.so (hipcc cross-compiles without a GPU)."""
-    srcs = [os.path.join(CSRC, f) for f in ("rdv_hip.hip", "rdv_device.h", "rdv_policy.h")] + \
-           [os.path.join(_PKG, "..", "include", "rdv.h")]
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(s) for s in srcs):
-        return LIB_PATH
+    """Compile csrc/rdv_hip.hip for gfx950 into librdv_hip.so (hipcc cross-compiles without a GPU).  `make` owns the dependency
+    list (every header of csrc/ and include/rdv.h): it is always asked, and rebuilds only what is out of date."""
     cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
     return LIB_PATH
@@ -105,13 +102,13 @@ def lib():
         "rdv_workspace_bytes": (i64, [i64, C.c_int]),
         "rdv_create": (C.c_int, [PP, i64, C.c_int, C.c_int, C.c_int, u64, u64, vp, C.POINTER(vp)]),
         "rdv_destroy": (C.c_int, [vp]),
-        "rdv_set_params": (C.c_int, [vp, PP]),
+        "rdv_set_params": (C.c_int, [vp, PP, vp]),
         "rdv_get_params": (C.c_int, [vp, PP]),
         "rdv_seed": (C.c_int, [vp, u64]),
         "rdv_set_reset_tape": (C.c_int, [vp, vp, i32]),
         "rdv_set_kernel_variant": (C.c_int, [vp, C.c_int]),
         "rdv_rigid_body_default": (C.c_int, [C.POINTER(RigidBody)]),
-        "rdv_set_rigid_body": (C.c_int, [vp, C.POINTER(RigidBody)]),
+        "rdv_set_rigid_body": (C.c_int, [vp, C.POINTER(RigidBody), vp]),
         "rdv_get_rigid_body": (C.c_int, [vp, C.POINTER(RigidBody)]),
         "rdv_reset": (C.c_int, [vp, vp, vp, vp]),
         "rdv_step": (C.c_int, [vp, vp, C.POINTER(StepOut), vp]),
@@ -121,7 +118,7 @@ def lib():
         "rdv_get_aux": (C.c_int, [vp, vp, vp]),
         "rdv_snapshot_bytes": (i64, [vp]),
         "rdv_snapshot": (C.c_int, [vp, vp, vp]),
-        "rdv_restore": (C.c_int, [vp, vp, vp]),
+        "rdv_restore": (C.c_int, [vp, vp, i64, vp]),
         "rdv_observe": (C.c_int, [vp, vp, vp]),
         "rdv_diagnose": (C.c_int, [vp, vp, vp]),
         "rdv_get_stats": (C.c_int, [vp, C.POINTER(Stats), C.c_int, vp]),

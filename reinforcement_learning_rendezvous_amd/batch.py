@@ -18,14 +18,14 @@ from .params import EnvParams, make_params
 
 _STORAGE = {"f32": N.STORAGE_F32, "f64": N.STORAGE_F64, N.STORAGE_F32: N.STORAGE_F32, N.STORAGE_F64: N.STORAGE_F64}
 _ON_DONE = {"reset": N.ON_DONE_RESET, "halt": N.ON_DONE_HALT, "continue": N.ON_DONE_CONTINUE}
-_VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT}
+_VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT, "inlane": N.VARIANT_INLANE}
 
 
 class RendezvousBatch:
     def __init__(self, num_envs, params: EnvParams = None, device="cuda:0", storage="f32", on_done="reset", seed=0,
                  env_id_offset=0, variant="auto", **env_kwargs):
         """``env_kwargs`` are the keyword arguments of the reference constructor (rendezvous_env.py:17-37).
-        ``variant`` ("auto" | "fused" | "split") selects the step kernel layout; results do not depend on it."""
+        ``variant`` ("auto" | "fused" | "split" | "inlane") selects the step kernel layout; results do not depend on it."""
         if params is not None and env_kwargs:
             raise TypeError("pass either params or the reference constructor's keyword arguments, not both")
         self.params = params.copy() if params is not None else make_params(**env_kwargs)
@@ -35,6 +35,7 @@ class RendezvousBatch:
         if not torch.cuda.is_available():
             raise N.RdvError(-2, "no HIP device visible to PyTorch (there is no CPU path)")
         self.num_envs = int(num_envs)
+        self.env_id_offset = int(env_id_offset)       # global index of local env 0 (sharded batches)
         self.storage = _STORAGE[storage]
         self.on_done = _ON_DONE[on_done]
         self._lib = N.lib()
@@ -133,10 +134,15 @@ class RendezvousBatch:
         self.obs.copy_(out["obs"][K - 1]); self.reward.copy_(out["reward"][K - 1]); self.done.copy_(out["done"][K - 1])
         return out
 
+    def act(self, policy, deterministic=False, out=None):
+        """``policy.act`` on the batch's current observation with the exploration noise keyed by GLOBAL env id (this shard's
+        ``env_id_offset``): ``act`` + ``step`` then gives what ``rollout`` gives, whatever the sharding."""
+        return policy.act(self.obs, deterministic=deterministic, out=out, env_id_offset=self.env_id_offset)
+
     def rollout(self, policy, n_steps, deterministic=False, out=None):
         """``n_steps`` of the closed loop  a_t ~ policy(obs_t); obs_{t+1}, r_t, done_t = step(clip(a_t))  in ONE kernel launch
         (the inner loop of SB3's ``collect_rollouts``, main.py:114): the env state stays in registers, observations and
-        actions in LDS.  Same results as ``policy.act`` + ``step`` called ``n_steps`` times.
+        actions in LDS.  Same results as ``self.act(policy)`` + ``step`` called ``n_steps`` times (noise keyed by global env id).
 
         Returns a dict of tensors shaped like SB3's RolloutBuffer rows: ``obs`` [T,N,17] (what the actor saw), ``actions``
         [T,N,6] (before clipping), ``reward`` [T,N], ``done`` [T,N] (uint8), ``log_prob`` [T,N], ``last_obs`` [N,17]; pass
@@ -195,7 +201,8 @@ class RendezvousBatch:
         """Back to a ``snapshot()`` (of a batch with the same number of envs and storage); the observation buffer follows."""
         if snap.numel() != int(self._lib.rdv_snapshot_bytes(self._h)) or snap.dtype != torch.uint8 or snap.device != self.device:
             raise ValueError("restore: not a snapshot of a batch of this size / storage on this device")
-        N.check(self._lib.rdv_restore(self._h, snap.contiguous().data_ptr(), self._stream()))
+        snap = snap.contiguous()
+        N.check(self._lib.rdv_restore(self._h, snap.data_ptr(), snap.numel(), self._stream()))
         self.obs.copy_(self.observe())
 
     def get_stats(self, reset=False):
@@ -220,7 +227,7 @@ class RendezvousBatch:
         N.check(self._lib.rdv_set_reset_tape(self._h, tape.data_ptr(), tape.shape[0]))
 
     def set_params(self, params: EnvParams):
-        N.check(self._lib.rdv_set_params(self._h, C.byref(params)))
+        N.check(self._lib.rdv_set_params(self._h, C.byref(params), self._stream()))
         self.params = params.copy()
 
     def set_rigid_body(self, inertia=None, inertia_target=None, torque=None, torque_target=None, integrator=None,
@@ -249,7 +256,7 @@ class RendezvousBatch:
             b.rtol = float(rtol)
         if atol is not None:
             b.atol = float(atol)
-        N.check(self._lib.rdv_set_rigid_body(self._h, C.byref(b)))
+        N.check(self._lib.rdv_set_rigid_body(self._h, C.byref(b), self._stream()))
 
     def get_rigid_body(self):
         b = N.RigidBody()

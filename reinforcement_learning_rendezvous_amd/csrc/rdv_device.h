@@ -489,74 +489,125 @@ __device__ __forceinline__ void deviate(const double* axis, double theta, const 
   o[3] = fma(a[0], b[3], fma(b[0], a[3], fma(a[1], b[2], -a[2] * b[1])));
 }
 
-// reset (:223-262): the new state and its collided/success flags, from (seed, env id, e.episode) or from a tape row.
-// Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
-template <typename ST>
-__device__ __forceinline__ void reset_state(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
+// One Philox block of the reset stream -> its six 21-bit uniforms u[6j .. 6j+5]
+__device__ __forceinline__ void reset_uniforms(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t j, double* u) {
+  uint32_t c0 = (uint32_t)env_id, c1 = (uint32_t)(env_id >> 32), c2 = episode, c3 = j;
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
+  u[6 * j + 0] = u21(c0 & 0x1FFFFFu); u[6 * j + 1] = u21(((c0 >> 21) | (c1 << 11)) & 0x1FFFFFu); u[6 * j + 2] = u21((c1 >> 10) & 0x1FFFFFu);
+  u[6 * j + 3] = u21(c2 & 0x1FFFFFu); u[6 * j + 4] = u21(((c2 >> 21) | (c3 << 11)) & 0x1FFFFFu); u[6 * j + 5] = u21((c3 >> 10) & 0x1FFFFFu);
+}
+
+// Which part of a new initial state a call computes.  The six sampled quantities of reset() are independent given their
+// uniforms (only wc needs R(qc) and wt needs R(qt), :256, :258), so the preparation of a next-episode state can be shared out
+// over several waves, each running a short instruction stream over the same list of envs (prepared-state slots,
+// csrc/rdv_slots.h): the expressions — hence the results, bit for bit — are those of the whole reset.
+enum ResetPart : int { RESET_ALL = -1, RESET_RC_VC = 0, RESET_QC_WC = 1, RESET_QT = 2, RESET_WT = 3 };
+
+// reset (:223-262): the new state (the fields of kPart; the others are left untouched) from (seed, env id, e.episode) or from a
+// tape row.  Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
+template <typename ST, int kPart>
+__device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
+  constexpr bool all = kPart == RESET_ALL;
+  constexpr bool do_rv = all || kPart == RESET_RC_VC, do_c = all || kPart == RESET_QC_WC, do_qt = all || kPart == RESET_QT || kPart == RESET_WT,
+                 do_wt = all || kPart == RESET_WT;
   if (tape_row) {
+    if (do_rv) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) e.rc[i] = tape_row[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) e.vc[i] = tape_row[3 + i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e.qc[i] = tape_row[6 + i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) e.wc[i] = tape_row[10 + i];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) e.qt[i] = tape_row[13 + i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) e.wt[i] = tape_row[17 + i];
-  } else {
-    double u[24];
-#pragma unroll
-    for (uint32_t j = 0; j < 4; ++j) {
-      uint32_t c0 = (uint32_t)env_id, c1 = (uint32_t)(env_id >> 32), c2 = e.episode, c3 = j;
-      philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
-      u[6 * j + 0] = u21(c0 & 0x1FFFFFu); u[6 * j + 1] = u21(((c0 >> 21) | (c1 << 11)) & 0x1FFFFFu); u[6 * j + 2] = u21((c1 >> 10) & 0x1FFFFFu);
-      u[6 * j + 3] = u21(c2 & 0x1FFFFFu); u[6 * j + 4] = u21(((c2 >> 21) | (c3 << 11)) & 0x1FFFFFu); u[6 * j + 5] = u21((c3 >> 10) & 0x1FFFFFu);
+      for (int i = 0; i < 3; ++i) { e.rc[i] = tape_row[i]; e.vc[i] = tape_row[3 + i]; }
     }
+    if (do_c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e.qc[i] = tape_row[6 + i];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e.wc[i] = tape_row[10 + i];
+    }
+    if (do_qt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) e.qt[i] = tape_row[13 + i];
+    }
+    if (do_wt) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) e.wt[i] = tape_row[17 + i];
+    }
+  } else {
+    // u[0..3] rc, u[4..7] vc, u[8..11] qc, u[12..15] wc, u[16..19] qt, u[20..23] wt; block j holds u[6j .. 6j+5]
+    double u[24];
+    if (do_rv) reset_uniforms(seed, env_id, e.episode, 0, u);
+    if (do_rv || do_c) reset_uniforms(seed, env_id, e.episode, 1, u);
+    if (do_c || do_qt) reset_uniforms(seed, env_id, e.episode, 2, u);
+    if (do_qt) reset_uniforms(seed, env_id, e.episode, 3, u);
     double dir[3], tmp[3], R[9];
-    unit_vector(u[0], u[1], u[2], dir);                                   // :231
-    { const double m = P.rc0_range * u[3];
+    if (do_rv) {
+      unit_vector(u[0], u[1], u[2], dir);                                   // :231
+      { const double m = P.rc0_range * u[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) e.rc[i] = fma(dir[i], m, P.nominal_rc0[i]); }   // :253
-    unit_vector(u[4], u[5], u[6], dir);                                   // :234
-    { const double m = P.vc0_range * u[7];
+        for (int i = 0; i < 3; ++i) e.rc[i] = fma(dir[i], m, P.nominal_rc0[i]); }   // :253
+      unit_vector(u[4], u[5], u[6], dir);                                   // :234
+      { const double m = P.vc0_range * u[7];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) e.vc[i] = fma(dir[i], m, P.nominal_vc0[i]); }   // :254
-    const double theta_c = P.qc0_range * u[8];                            // :237
-    unit_vector(u[9], u[10], u[11], dir);                                 // :238
-    deviate(dir, theta_c, P.nominal_qc0, e.qc);                           // :239, :255
-    unit_vector(u[12], u[13], u[14], dir);                                // :242
-    { const double m = P.wc0_range * u[15];
+        for (int i = 0; i < 3; ++i) e.vc[i] = fma(dir[i], m, P.nominal_vc0[i]); }   // :254
+    }
+    if (do_c) {
+      const double theta_c = P.qc0_range * u[8];                            // :237
+      unit_vector(u[9], u[10], u[11], dir);                                 // :238
+      deviate(dir, theta_c, P.nominal_qc0, e.qc);                           // :239, :255
+      unit_vector(u[12], u[13], u[14], dir);                                // :242
+      { const double m = P.wc0_range * u[15];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) tmp[i] = fma(dir[i], m, P.nominal_wc0[i]); }
-    quat2mat(e.qc, R); matTvec(R, tmp, e.wc);                             // :256 lvlh2chaser
-    const double theta_t = P.qt0_range * u[16];                           // :245
-    unit_vector(u[17], u[18], u[19], dir);                                // :246
-    deviate(dir, theta_t, P.nominal_qt0, e.qt);                           // :247, :257
-    unit_vector(u[20], u[21], u[22], dir);                                // :250
-    { const double m = P.wt0_range * u[23];
+        for (int i = 0; i < 3; ++i) tmp[i] = fma(dir[i], m, P.nominal_wc0[i]); }
+      quat2mat(e.qc, R); matTvec(R, tmp, e.wc);                             // :256 lvlh2chaser
+    }
+    if (do_qt) {
+      const double theta_t = P.qt0_range * u[16];                           // :245
+      unit_vector(u[17], u[18], u[19], dir);                                // :246
+      deviate(dir, theta_t, P.nominal_qt0, e.qt);                           // :247, :257
+    }
+    if (do_wt) {
+      unit_vector(u[20], u[21], u[22], dir);                                // :250
+      { const double m = P.wt0_range * u[23];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) tmp[i] = fma(dir[i], m, P.nominal_wt0[i]); }
-    quat2mat(e.qt, R); matTvec(R, tmp, e.wt);                             // :258 lvlh2target
+        for (int i = 0; i < 3; ++i) tmp[i] = fma(dir[i], m, P.nominal_wt0[i]); }
+      quat2mat(e.qt, R); matTvec(R, tmp, e.wt);                             // :258 lvlh2target
+    }
   }
   const ST tag = ST(0);
+  if (do_rv) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) { e.rc[i] = canon(e.rc[i], tag); e.vc[i] = canon(e.vc[i], tag); e.wc[i] = canon(e.wc[i], tag); e.wt[i] = canon(e.wt[i], tag); }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { e.qc[i] = canon(e.qc[i], tag); e.qt[i] = canon(e.qt[i], tag); }
-  // :261-262 collided = check_collision(), success = int(check_success()).  Both need the chaser within
-  // max(koz_radius, |rd| + max_rd_error) of the target (inside the KOZ sphere, resp. position error <= max_rd_error);
-  // the nominal start is 10 m out, so the rotation matrices and errors are only built for states that close.
-  e.flags = 0u;
-  if (dot3(e.rc, e.rc) < P.reset_flag_radius2) {
-    Derived d;
-    derive<true>(P, e, d);
-    const bool coll = in_koz(P, d);
-    const bool succ = !coll && errors_ok(P, d);
-    e.flags = (coll ? FLAG_COLLIDED : 0u) | ((succ ? 1u : 0u) << SUCCESS_SHIFT);
+    for (int i = 0; i < 3; ++i) { e.rc[i] = canon(e.rc[i], tag); e.vc[i] = canon(e.vc[i], tag); }
   }
+  if (do_c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e.wc[i] = canon(e.wc[i], tag);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.qc[i] = canon(e.qc[i], tag);
+  }
+  if (do_qt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.qt[i] = canon(e.qt[i], tag);
+  }
+  if (do_wt) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e.wt[i] = canon(e.wt[i], tag);
+  }
+}
+
+// :261-262 collided = check_collision(), success = int(check_success()) of a complete new state.  Both need the chaser within
+// max(koz_radius, |rd| + max_rd_error) of the target (inside the KOZ sphere, resp. position error <= max_rd_error);
+// the nominal start is 10 m out, so the rotation matrices and errors are only built for states that close.
+__device__ __forceinline__ bool reset_flags_needed(const DevParams& P, const Env& e) { return dot3(e.rc, e.rc) < P.reset_flag_radius2; }
+__device__ __forceinline__ uint32_t reset_flags(const DevParams& P, const Env& e) {
+  Derived d;
+  derive<true>(P, e, d);
+  const bool coll = in_koz(P, d);
+  const bool succ = !coll && errors_ok(P, d);
+  return (coll ? FLAG_COLLIDED : 0u) | ((succ ? 1u : 0u) << SUCCESS_SHIFT);
+}
+
+template <typename ST>
+__device__ __forceinline__ void reset_state(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
+  reset_fields<ST, RESET_ALL>(P, e, seed, env_id, tape_row);
+  e.flags = 0u;
+  if (reset_flags_needed(P, e)) e.flags = reset_flags(P, e);
 }
 
 // the bookkeeping half of reset (:263-266)

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -124,6 +125,9 @@ struct StepArgs {
   uint64_t env_id_offset;
   int32_t tape_depth;
   int32_t on_done;
+  void* prep;               // prepared next-episode states (csrc/rdv_slots.h): chunk arrays [7][N]
+  float4* prep_obs;         // their observations [5][N]
+  uint32_t* prep_tag;       // [N]
 #ifdef RDV_STAMPS
   unsigned long long* stamps;
 #endif
@@ -280,8 +284,9 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fused variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).
-// The right shape when the chip is full (several waves per SIMD): no work is done twice.
+// In-lane variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).  Round 1's
+// fused kernel; now the kernel of the cold configurations only — evaluator diagnostics (kDiag), general rigid bodies (kGeneral),
+// the first step after rdv_set_state (kRaw).  It does not use the prepared-state slots (the host re-prepares them afterwards).
 // kGeneral: general rigid bodies (rdv_set_rigid_body) — the attitude of both bodies is integrated with the reference's RK45
 // scheme instead of the closed form, and the target's rate is part of the state that is written back.
 // kRaw: the first step after rdv_set_state (quaternions that need not be normalised, see integrate_attitude).
@@ -344,42 +349,175 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   if (stepped) store_env<ST>(ws, n, i, e, did_reset || kGeneral);
 }
 
+}  // namespace rdv
+#include "rdv_slots.h"
+namespace rdv {
+
 // ---------------------------------------------------------------------------------------------------------------
-// Split-role variant for a chip that is NOT full (N <= ~128k envs is at most two waves per SIMD): a 512-thread workgroup
-// owns 256 envs.  Waves 0-3 ("step waves") do the whole transition for their 64 envs exactly as the fused kernel does,
-// except the in-lane reset.  Waves 4-7 ("service waves") run beside them — an 8-wave workgroup places waves w and w+4 on
-// the same SIMD, so every SIMD holds one of each — and compute every env's NEXT initial state and observation while the
-// step runs (they depend only on seed, env id and episode index).  After the single workgroup barrier a service lane
-// whose env finished writes that state and observation straight to HBM; the step waves have nothing left to do.
-// Same arithmetic, same results as the fused variant (tests run both).  The next-state work is done for every env and
-// used by ~5 %: it costs issue slots that are idle at this size, and takes the reset (as long as the step itself)
-// off the critical path.
+// Fused variant (the chip is full: several waves per SIMD, N > ~98k envs): every wave does the whole transition for its 64 envs.
+// A lane whose episode ends copies its prepared slot (rdv_slots.h) and marks it — no reset arithmetic, no barrier, no second role
+// in the step path.  The marked slots are refilled by refill_kernel, launched right behind on the same stream: it finds them by
+// their tags and runs the reset DENSELY (one wave compacts the marks of 1,024 envs: ~51 per step with random actions, one pass at
+// ~80 % lane use), i.e. the reset costs ~5 % of a step's instructions instead of the ~40 % of the divergent in-lane form.
+// kMinWaves: waves per SIMD the register allocation is held to (256-thread workgroups: 3 -> 168 VGPRs, 4 -> 128).
+template <typename ST>
+__device__ __forceinline__ SlotStore<ST> hbm_slots(const StepArgs& A) {
+  SlotStore<ST> S;
+  S.chunks = reinterpret_cast<typename Vec4<ST>::type*>(A.prep); S.obs = A.prep_obs; S.n = A.n;
+  return S;
+}
+
+// The whole reset of episode `counter` into env i's slot (one lane per env): refill_kernel, prepare_kernel, reset_kernel.
+template <typename ST>
+__device__ __forceinline__ void refill_whole(const StepArgs& A, const DevParams& P, int64_t i, uint32_t counter) {
+  Env ne;
+  float o[RDV_OBS_DIM];
+  reset_whole<ST>(P, ne, o, A.seed, A.env_id_offset + (uint64_t)i, counter, tape_row_of(A.tape, A.tape_depth, A.n, i, counter));
+  slot_store_full<ST>(hbm_slots<ST>(A), i, ne, o);
+  A.prep_tag[i] = counter + 1u;
+}
+
+template <typename ST, int kMinWaves>
+__global__ __launch_bounds__(kBlock, kMinWaves) void step_kernel_fused(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+                                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
+  StepArgs A = A_rest;   // the seven hot arguments are preloaded into SGPRs (see step_kernel)
+  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
+  using V = typename Vec4<ST>::type;
+  __shared__ __attribute__((aligned(16))) float lds[kBlock * RDV_OBS_DIM];   // 17,408 B: wave-private staging regions
+  const DevParams& P = *Pp;   // scalar loads: see step_kernel
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t wave_base = i - lane;
+  const int64_t n = A.n;
+  const bool active = i < n;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
+  V* ws = reinterpret_cast<V*>(A.ws);
+
+  Env e;
+  if (active) load_env<ST>(ws, n, i, e);
+  uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
+  const uint64_t slot_pre = stats_preload(slot, lane);
+  float a[RDV_ACT_DIM];
+  load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+
+  StepResult r;
+  const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
+  const bool fin = stepped && r.done;
+  stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+  store_step_outputs<true>(A, i, active, fin, r, e);
+  const bool take = fin && A.on_done == RDV_ON_DONE_RESET;
+  if (take) {   // auto-reset (SB3 DummyVecEnv semantics): the env continues from its prepared slot, the observation is the slot's
+    SlotRaw<ST> raw;
+    slot_fetch<ST>(hbm_slots<ST>(A), i, raw);      // 12 sparse 16-byte loads (the other waves of the SIMD cover their latency)
+    slot_unpack<ST>(P, raw, e, r.obs);
+    A.prep_tag[i] = e.episode | kTagConsumed;      // every slot is clean when this kernel starts (the host sees to it)
+  } else if (fin && A.on_done == RDV_ON_DONE_HALT) {
+    e.flags |= FLAG_HALTED;
+  }
+  // observations: own row -> LDS (stride 17: conflict-free) -> contiguous stores
+#pragma unroll
+  for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
+  wave_lds_fence();
+  store_obs_rows(A.obs, wave_base, rows, lane, wl);
+  // state write-back: 6 x 16-byte-per-lane stores (7 where a slot was taken: wt)
+  if (stepped) store_env<ST>(ws, n, i, e, take);
+}
+
+// Refill of the marked slots.  One wave owns 1,024 consecutive envs: 16 tags per lane (4 x 16-byte loads), the marked ones are
+// compacted into a wave-private LDS list, and the whole reset runs once per 64 of them.
+constexpr int kRefillPerWave = 1024;
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void refill_kernel(const DevParams* __restrict__ Pp, const StepArgs A) {
+  __shared__ uint16_t lists[kBlock / kWave][kRefillPerWave];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  uint16_t* list = lists[wave_in_block];
+  const int64_t base = ((int64_t)blockIdx.x * (kBlock / kWave) + wave_in_block) * kRefillPerWave;
+  const int64_t n = A.n;
+  if (base >= n) return;   // wave-uniform
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int first = (q * kWave + lane) * 4;     // this lane's four consecutive entries
+    uint32_t t[4] = {0u, 0u, 0u, 0u};
+    if (base + first + 3 < n && (n & 3) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4*>(A.prep_tag + base + first);
+      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (base + first + c < n) t[c] = A.prep_tag[base + first + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bool marked = (t[c] & kTagConsumed) != 0u;
+      const unsigned long long m = __ballot(marked);
+      if (marked) {
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        list[total + rank] = (uint16_t)(first + c);
+      }
+      total += __popcll(m);
+    }
+  }
+  wave_lds_fence();
+#pragma clang loop unroll(disable)
+  for (int j0 = 0; j0 < total; j0 += kWave) {
+    const int j = j0 + lane;
+    if (j < total) {
+      const int64_t i = base + list[j];
+      refill_whole<ST>(A, *Pp, i, A.prep_tag[i] & ~kTagConsumed);
+    }
+  }
+}
+
+// Slots of all envs (after rdv_create + first reset they are written by reset_kernel; this kernel re-derives all of them from the
+// envs' current episode indices when something outside the step kernels changed what a reset returns: parameters, tape, restore,
+// or a launch of the in-lane kernels, which do not maintain them).
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __restrict__ Pp, const StepArgs A) {
+  using V = typename Vec4<ST>::type;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= A.n) return;
+  const V c5 = reinterpret_cast<const V*>(A.ws)[5 * A.n + i];
+  refill_whole<ST>(A, *Pp, i, s2u(c5.w));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Split-role variant for a chip that is NOT full (N <= ~98k envs: one transition wave per SIMD): a 512-thread workgroup owns 256
+// envs.  Waves 0-3 ("step waves") do the whole transition for their 64 envs; a lane whose episode ends copies its prepared slot
+// and marks it (after the barrier).  Waves 4-7 ("service waves", one per SIMD beside a step wave) refill the slots the PREVIOUS
+// launch marked — typically 13 of the workgroup's 256 — while the step runs, sharing the work BY PART (wave 4: rc, vc + bookkeeping;
+// 5: qc, wc; 6: qt; 7: wt): every SIMD runs a ~300-instruction stream over the same compacted list instead of the whole
+// ~900-instruction reset for each of its 64 lanes (round 1).  One workgroup barrier: slots are refilled before it, marked after it.
+// An env that ends again in the launch that refills its slot (an episode of one step) takes the slot after the barrier.
 constexpr int kSplitEnvs = 256;      // envs per workgroup
 constexpr int kSplitBlock = 512;     // 8 waves
+constexpr int kSplitWaves = kSplitEnvs / kWave;
 
-template <typename ST, bool kDiag>
+template <typename ST>
 __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
-  // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
-  // at wave launch (-mllvm -amdgpu-kernarg-preload-count=16) instead of being fetched from the host-visible kernarg
-  // segment; the rest of the argument block is read later, off the critical path.
-  StepArgs A = A_rest;
+  StepArgs A = A_rest;   // the seven hot arguments are preloaded into SGPRs (see step_kernel)
   A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
   using V = typename Vec4<ST>::type;
   __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // actions, then observation rows
-  __shared__ unsigned long long fin_mask[kSplitEnvs / kWave];                        // per step wave: lanes to reset
+  __shared__ uint16_t job_list[kSplitWaves][kSplitEnvs];                             // wave-private lists of the service waves
+  __shared__ uint32_t job_counter[kSplitWaves][kSplitEnvs];
   const DevParams& P = *Pp;   // scalar loads: see step_kernel
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
-  const bool step_role = wv < kSplitEnvs / kWave;
-  const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);          // both roles: the env this lane is responsible for
-  const int64_t i = (int64_t)blockIdx.x * kSplitEnvs + slot_in_block;
+  const bool step_role = wv < kSplitWaves;
+  const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);
+  const int64_t block_base = (int64_t)blockIdx.x * kSplitEnvs;
+  const int64_t i = block_base + slot_in_block;
   const int64_t wave_base = i - lane;
   const int64_t n = A.n;
   const bool active = i < n;
   const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
   V* ws = reinterpret_cast<V*>(A.ws);
   const bool resets = A.on_done == RDV_ON_DONE_RESET;
+  const SlotStore<ST> S = hbm_slots<ST>(A);
   RDV_STAMP_DECL
   RDV_STAMP(0);
 
@@ -389,92 +527,118 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     Env e;
     StepResult r;
     if (active) load_env<ST>(ws, n, i, e);
+    uint32_t tag = 0u;
+    if (resets && active) tag = A.prep_tag[i];
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
     const uint64_t slot_pre = stats_preload(slot, lane);
     float a[RDV_ACT_DIM];
     load_actions(A.actions, wave_base, rows, lane, active, wl, a);
     RDV_STAMP(1);
-    const bool stepped = advance<ST, kDiag>(A, P, i, active, e, a, r);
+    const bool marked = (tag & kTagConsumed) != 0u;   // the service waves refill this slot during this launch
+    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     const bool to_reset = fin && resets;
-    const unsigned long long m_reset = __ballot(to_reset);
-    if (lane == 0) fin_mask[wv] = m_reset;
+    const bool take = to_reset && !marked;
+    const bool late = to_reset && marked;
+    const unsigned long long m_late = __ballot(late);
+    SlotRaw<ST> raw;
+    if (take) slot_fetch<ST>(S, i, raw);      // 12 sparse 16-byte loads, in flight during the statistics and the output stores
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
     store_step_outputs<true>(A, i, active, fin, r, e);
     RDV_STAMP(3);
-    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-    // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores.  If an env of this wave resets,
-    // the rows stay in LDS: the service wave swaps in the reset observation and stores the block after the barrier.
+    if (take) slot_unpack<ST>(P, raw, e, r.obs);   // auto-reset (SB3 DummyVecEnv semantics): the first observation of the next episode
+    else if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+    // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores
 #pragma unroll
     for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
     wave_lds_fence();
-    if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
+    if (m_late == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
     RDV_STAMP(4);
-    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
+    if (stepped && !late) store_env<ST>(ws, n, i, e, take);   // 6 x 16-byte-per-lane stores (7 where a slot was taken)
     RDV_STAMP(5);
+    __syncthreads();
     RDV_STAMP(6);
-    __syncthreads();
-  } else {
-    // ------------------------------------------------------------------ service waves
-    V packed[7];               // the next initial state, already in storage layout: nothing is left to compute after the barrier
-    float robs[RDV_OBS_DIM];
-    if (resets && active) {
-      Env ne;
-      const V c5 = ws[5 * n + i];
-      ne.episode = s2u(c5.w);
-      RDV_STAMP(1);
-      const double* row = nullptr;
-      if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
-      reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
-      reset_aux<ST>(P, ne);
-      observation(P, ne, robs);
-      pack_env<ST>(ne, packed);
-      RDV_STAMP(2);
-    }
-    RDV_STAMP(3);
-    __syncthreads();
-    RDV_STAMP(4);
-    const unsigned long long m_reset = fin_mask[wv - kSplitEnvs / kWave];
-    if (m_reset != 0ull) {   // wave-uniform: some env of the step wave we serve finished its episode
-      float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
-      if (active && ((m_reset >> lane) & 1ull)) {
-        // auto-reset (SB3 DummyVecEnv semantics): the new state to HBM, the first observation of the next episode into the row
-        store_chunks<ST>(ws, n, i, packed, true);
+    // tags: this lane is the only writer of its env's tag in this launch
+    if (take) A.prep_tag[i] = e.episode | kTagConsumed;
+    else if (marked && !late) A.prep_tag[i] = (tag & ~kTagConsumed) + 1u;          // refilled before the barrier: clean again
+    if (m_late != 0ull) {   // wave-uniform, rare: an episode of a single step
+      if (late) {
+        slot_fetch<ST>(S, i, raw);            // written by the service waves of this workgroup before the barrier
+        slot_unpack<ST>(P, raw, e, r.obs);
 #pragma unroll
-        for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
+        for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
       }
       wave_lds_fence();
       store_obs_rows(A.obs, wave_base, rows, lane, wl);
+      if (late) {
+        store_env<ST>(ws, n, i, e, true);
+        A.prep_tag[i] = e.episode | kTagConsumed;
+      }
     }
+  } else {
+    // ------------------------------------------------------------------ service waves
+    const int role = wv - kSplitWaves;
+    if (resets) {
+      bool pend[kSplitWaves];
+      uint32_t tg[kSplitWaves];
+#pragma unroll
+      for (int q = 0; q < kSplitWaves; ++q) {   // the tags of the workgroup's 256 envs, four per lane
+        const int64_t idx = block_base + q * kWave + lane;
+        tg[q] = idx < n ? A.prep_tag[idx] : 0u;
+        pend[q] = (tg[q] & kTagConsumed) != 0u;
+      }
+      RDV_STAMP(1);
+      const int total = compact_flags<kSplitWaves>(pend, lane, job_list[role]);
+      if (total > 0) {   // wave-uniform
+#pragma unroll
+        for (int q = 0; q < kSplitWaves; ++q)
+          if (pend[q]) job_counter[role][q * kWave + lane] = tg[q] & ~kTagConsumed;
+        wave_lds_fence();
+#pragma clang loop unroll(disable)
+        for (int j0 = 0; j0 < total; j0 += kWave) {
+          const int j = j0 + lane;
+          if (j < total) {
+            const int s = (int)job_list[role][j];
+            const uint32_t counter = job_counter[role][s];
+            const int64_t ii = block_base + s;
+            slot_refill_role<ST>(role, P, S, ii, A.seed, A.env_id_offset + (uint64_t)ii, counter, tape_row_of(A.tape, A.tape_depth, n, ii, counter));
+          }
+        }
+      }
+      RDV_STAMP(2);
+    }
+    RDV_STAMP(3);
+    __syncthreads();   // (release: the refilled parts are in memory before a step lane may take them)
+    RDV_STAMP(4);
     RDV_STAMP(6);
   }
   RDV_STAMP(7);
   RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + wv)
 }
 
-// reset() for all envs or where mask != 0
+// reset() for all envs or where mask != 0; the env's prepared slot is refilled for the episode after the one that starts here
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams P, void* ws_, int64_t n, const uint8_t* mask,
-                                                       float* obs, const double* tape, int32_t tape_depth, uint64_t seed,
-                                                       uint64_t env_id_offset, int fresh) {
+__global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams* __restrict__ Pp, const StepArgs A, const uint8_t* mask, float* obs, int fresh) {
   using V = typename Vec4<ST>::type;
+  const DevParams& P = *Pp;
+  const int64_t n = A.n;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
-  V* ws = reinterpret_cast<V*>(ws_);
+  V* ws = reinterpret_cast<V*>(A.ws);
   if (mask && !mask[i]) return;
   Env e;
   load_env<ST>(ws, n, i, e);
   if (fresh) e.episode = 0;   // first reset after create/seed: the workspace may hold anything
-  const double* row = nullptr;
-  if (tape_depth > 0) row = tape + ((int64_t)(e.episode % (uint32_t)tape_depth) * n + i) * RDV_STATE_DIM;
-  reset_env<ST>(P, e, seed, env_id_offset + (uint64_t)i, row);
+  const uint32_t counter = e.episode;
+  reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, tape_row_of(A.tape, A.tape_depth, n, i, counter));
   store_env<ST>(ws, n, i, e, true);
   if (obs) {
     float o[RDV_OBS_DIM];
     observation(P, e, o);
     for (int j = 0; j < RDV_OBS_DIM; ++j) obs[i * RDV_OBS_DIM + j] = o[j];
   }
+  refill_whole<ST>(A, P, i, counter + 1u);
 }
 
 enum { ACC_SET_STATE = 0, ACC_GET_STATE, ACC_GET_AUX, ACC_OBSERVE, ACC_DIAGNOSE };
@@ -519,6 +683,16 @@ __global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void*
 #include "rdv_step_many.h"
 namespace rdv {
 
+// The derived parameter block travels as a kernel argument and is written by the device: ordered on the caller's stream like
+// every other launch (a hipMemcpy from host memory is ordered against the legacy stream only, not against PyTorch's non-blocking
+// side streams) and legal inside a stream capture (the values are baked into the graph node).
+__global__ __launch_bounds__(kWave) void params_kernel(const DevParams src, DevParams* dst) {
+  const uint32_t* from = reinterpret_cast<const uint32_t*>(&src);
+  uint32_t* to = reinterpret_cast<uint32_t*>(dst);
+  for (int k = threadIdx.x; k < (int)(sizeof(DevParams) / 4); k += kWave) to[k] = from[k];
+}
+static_assert(sizeof(DevParams) % 4 == 0 && sizeof(DevParams) <= 3072, "DevParams is passed by value to params_kernel");
+
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 static thread_local char g_err[512] = "";
@@ -543,6 +717,9 @@ static inline int64_t stats_bytes(int64_t n) { return align_up(n_waves(n) * kSta
 static inline int64_t params_bytes() { return align_up((int64_t)sizeof(DevParams), 256); }
 constexpr int kAcosEntries = 200001;   // acos(k/1e5), k = -100000..100000 (general.py:179 rounds every cosine to 5 decimals)
 static inline int64_t acos_bytes() { return align_up((int64_t)kAcosEntries * (int64_t)sizeof(double), 256); }
+// prepared next-episode states (rdv_slots.h): 7 chunk arrays like the state, 5 float4 observation arrays, one tag per env
+static inline int64_t prep_obs_bytes(int64_t n) { return align_up(kSlotObsVecs * n * 16, 256); }
+static inline int64_t prep_tag_bytes(int64_t n) { return align_up(n * 4, 256); }
 
 // Largest integer k in [-100000, 100000] for which acos(k/1e5) > theta (strict) or >= theta; -100001 if there is none.
 // acos(k/1e5) is what general.py:179 evaluates for every cosine that rounds to k*1e-5, so comparing k with this
@@ -640,6 +817,12 @@ struct RdvEnvBatch {
   RdvRigidBody body; // rdv_set_rigid_body
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
   bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
+  void* prep;        // prepared next-episode states (rdv_slots.h): chunk arrays, observations, tags
+  float4* prep_obs;
+  uint32_t* prep_tag;
+  bool prepared_ok;  // every slot holds what the env's next reset returns (false: prepare_kernel runs before the next slot-using launch)
+  bool tags_clean;   // no slot is marked "taken, refill pending" (step_kernel_split leaves marks for the next launch to refill)
+  int fused_min_waves;   // tuning: register budget of step_kernel_fused (3 or 4 waves per SIMD)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
@@ -650,6 +833,46 @@ static void apply_rigid_body(RdvEnvBatch* h);
 
 #define RDV_CHECK_HANDLE(h) \
   if (!(h) || (h)->magic != kMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_handle")
+
+// the arguments every env kernel shares (the callers add their I/O pointers)
+static void base_args(const RdvEnvBatch* h, StepArgs& A) {
+  std::memset(&A, 0, sizeof A);
+  A.ws = h->ws; A.stats = h->stats; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
+  A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.prep = h->prep; A.prep_obs = h->prep_obs; A.prep_tag = h->prep_tag;
+}
+static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
+
+// The slot-using kernels (step_kernel_fused / _split, step_many_kernel, rollout_kernel) rely on every slot holding what the env's
+// next reset returns.  Whatever changes that from outside them (parameters, tape, restore, a launch of the in-lane kernels) clears
+// prepared_ok; the slots are then re-derived here, on the caller's stream, before the next such launch.
+static int ensure_prepared(RdvEnvBatch* h, hipStream_t s) {
+  if (h->on_done != RDV_ON_DONE_RESET || h->prepared_ok) return RDV_OK;
+  StepArgs A;
+  base_args(h, A);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(prepare_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, A);
+  else hipLaunchKernelGGL(prepare_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, A);
+  RDV_HIP(hipGetLastError());
+  h->prepared_ok = true; h->tags_clean = true;
+  return RDV_OK;
+}
+// refill_kernel: every marked slot is refilled (the fused step kernel starts from clean slots and is followed by this)
+static int refill_marked(RdvEnvBatch* h, hipStream_t s) {
+  StepArgs A;
+  base_args(h, A);
+  const int64_t per_block = (int64_t)kRefillPerWave * (kBlock / kWave);
+  const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(refill_kernel<float>, grid, dim3(kBlock), 0, s, h->dev_params, A);
+  else hipLaunchKernelGGL(refill_kernel<double>, grid, dim3(kBlock), 0, s, h->dev_params, A);
+  RDV_HIP(hipGetLastError());
+  h->tags_clean = true;
+  return RDV_OK;
+}
+// the derived parameter block -> device, ordered on `s` (params_kernel)
+static int upload_params(RdvEnvBatch* h, hipStream_t s) {
+  hipLaunchKernelGGL(params_kernel, dim3(1), dim3(kWave), 0, s, h->dev, h->dev_params);
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
+}
 
 extern "C" {
 
@@ -695,7 +918,8 @@ int rdv_params_validate(const RdvParams* p) {
 
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
   if (n_envs <= 0 || (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64)) return -1;
-  return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes() + acos_bytes();
+  return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes() + acos_bytes() +
+         chunk_bytes(n_envs, storage) + prep_obs_bytes(n_envs) + prep_tag_bytes(n_envs);
 }
 
 int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
@@ -838,16 +1062,19 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_policy_act + rdv_step");
   DeviceGuard guard(h->device);
   h->raw_state = false;   // the rollout kernel integrates injected (unnormalised) quaternions itself
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = ensure_prepared(h, s)) return rc;
   RolloutArgs A;
   A.ws = h->ws; A.stats = h->stats; A.obs = out->obs; A.actions = out->actions; A.reward = out->reward; A.done = out->done;
   A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.seed = h->seed;
+  A.prep = h->prep; A.prep_obs = h->prep_obs; A.prep_tag = h->prep_tag;
   A.env_id_offset = h->env_id_offset; A.noise_seed = noise_seed; A.noise_counter0 = noise_counter0;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps; A.deterministic = deterministic ? 1 : 0;
   const dim3 grid((unsigned)((h->n + kRollEnvs - 1) / kRollEnvs)), block(kRollBlock);
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(rollout_kernel<float>, grid, block, kRollLdsBytes, s, h->dev_params, p->weights, A);
-  else hipLaunchKernelGGL(rollout_kernel<double>, grid, block, kRollLdsBytes, s, h->dev_params, p->weights, A);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(rollout_kernel<float>, grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
+  else hipLaunchKernelGGL(rollout_kernel<double>, grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
   RDV_HIP(hipGetLastError());
+  h->tags_clean = true;   // the persistent kernels refill marked slots before their first use and hand every slot back clean
   return RDV_OK;
 }
 
@@ -882,19 +1109,32 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->stats = reinterpret_cast<uint64_t*>(static_cast<char*>(h->ws) + chunk_bytes(n_envs, storage));
   h->dev_params = reinterpret_cast<DevParams*>(reinterpret_cast<char*>(h->stats) + stats_bytes(n_envs));
   h->acos_table = reinterpret_cast<double*>(reinterpret_cast<char*>(h->dev_params) + params_bytes());
+  h->prep = reinterpret_cast<char*>(h->acos_table) + acos_bytes();
+  h->prep_obs = reinterpret_cast<float4*>(static_cast<char*>(h->prep) + chunk_bytes(n_envs, storage));
+  h->prep_tag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h->prep_obs) + prep_obs_bytes(n_envs));
+  h->prepared_ok = false; h->tags_clean = true; h->fused_min_waves = 3;
+  if (const char* v = std::getenv("RDV_FUSED_MIN_WAVES")) h->fused_min_waves = std::atoi(v) == 4 ? 4 : 3;   // tuning knob
   h->dev.acos_table = h->acos_table;
+  // every step of the set-up reports itself: which call failed, and why
+  const char* what = "hipMemset of the workspace";
   hipError_t err = hipMemset(h->ws, 0, (size_t)bytes);
   if (err == hipSuccess) {
+    what = "hipMemcpy of the acos table";
     std::vector<double> table((size_t)kAcosEntries);
     for (int k = 0; k < kAcosEntries; ++k) table[(size_t)k] = std::acos((double)(k - 100000) / 1e5);   // the oracle's expression
     err = hipMemcpy(h->acos_table, table.data(), table.size() * sizeof(double), hipMemcpyHostToDevice);
   }
-  if (err == hipSuccess) err = hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice);
-  // the rollout kernel uses 78 KiB of dynamic LDS (above the 64 KiB default limit); raised here, outside any stream capture
-  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes);
-  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, kRollLdsBytes);
-  if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<double>());
-  if (err != hipSuccess) { if (h->own_ws) (void)hipFree(h->ws); delete h; return fail(RDV_ERR_HIP, "hipMemset of the workspace failed: %s", hipGetErrorString(err)); }
+  if (err == hipSuccess) { what = "hipMemcpy of the parameter block"; err = hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice); }
+  // the persistent kernels use more dynamic LDS than the 64 KiB default limit; raised here, outside any stream capture
+  if (err == hipSuccess) { what = "hipFuncSetAttribute(rollout_kernel<float>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, roll_lds_bytes<float>()); }
+  if (err == hipSuccess) { what = "hipFuncSetAttribute(rollout_kernel<double>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, roll_lds_bytes<double>()); }
+  if (err == hipSuccess) { what = "hipFuncSetAttribute(step_many_kernel<float>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<float>()); }
+  if (err == hipSuccess) { what = "hipFuncSetAttribute(step_many_kernel<double>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<double>()); }
+  if (err != hipSuccess) {
+    if (h->own_ws) (void)hipFree(h->ws);
+    delete h;
+    return fail(err == hipErrorOutOfMemory ? RDV_ERR_OUT_OF_MEMORY : RDV_ERR_HIP, "rdv_create: %s failed: %s", what, hipGetErrorString(err));
+  }
   h->host_slots.resize((size_t)(n_waves(n_envs) * kStatWords));
   *out = h;
   return RDV_OK;
@@ -973,15 +1213,14 @@ static void apply_rigid_body(RdvEnvBatch* h) {   // h->body (validated) -> the k
   }
   h->dev.rk_rtol = b.rtol; h->dev.rk_atol = b.atol;
 }
-int rdv_set_rigid_body(rdv_handle h, const RdvRigidBody* b) {
+int rdv_set_rigid_body(rdv_handle h, const RdvRigidBody* b, void* stream) {
   RDV_CHECK_HANDLE(h);
   bool general = false;
   if (int rc = validate_rigid_body(b, &general)) return rc;
   DeviceGuard guard(h->device);
   h->body = *b; h->general = general;
   apply_rigid_body(h);
-  RDV_HIP(hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice));
-  return RDV_OK;
+  return upload_params(h, static_cast<hipStream_t>(stream));
 }
 int rdv_get_rigid_body(rdv_handle h, RdvRigidBody* out) {
   RDV_CHECK_HANDLE(h);
@@ -990,16 +1229,15 @@ int rdv_get_rigid_body(rdv_handle h, RdvRigidBody* out) {
   return RDV_OK;
 }
 
-int rdv_set_params(rdv_handle h, const RdvParams* p) {
+int rdv_set_params(rdv_handle h, const RdvParams* p, void* stream) {
   RDV_CHECK_HANDLE(h);
   if (int rc = rdv_params_validate(p)) return rc;
   DeviceGuard guard(h->device);
   h->params = *p; derive_params(*p, h->dev);
   h->dev.acos_table = h->acos_table;
   apply_rigid_body(h);
-  // blocking copy on the legacy default stream: ordered after work already enqueued on blocking streams
-  RDV_HIP(hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice));
-  return RDV_OK;
+  h->prepared_ok = false;   // nominal state / ranges may have changed: what a reset returns is no longer what the slots hold
+  return upload_params(h, static_cast<hipStream_t>(stream));
 }
 int rdv_get_params(rdv_handle h, RdvParams* out) {
   RDV_CHECK_HANDLE(h);
@@ -1009,7 +1247,7 @@ int rdv_get_params(rdv_handle h, RdvParams* out) {
 }
 int rdv_seed(rdv_handle h, uint64_t seed) {
   RDV_CHECK_HANDLE(h);
-  h->seed = seed; h->fresh = true;
+  h->seed = seed; h->fresh = true; h->prepared_ok = false;
   return RDV_OK;
 }
 #ifdef RDV_STAMPS
@@ -1021,7 +1259,7 @@ int rdv_debug_set_stamps(rdv_handle h, unsigned long long* stamps) {   // diagno
 #endif
 int rdv_set_kernel_variant(rdv_handle h, int variant) {
   RDV_CHECK_HANDLE(h);
-  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT)
+  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT && variant != RDV_VARIANT_INLANE)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_kernel_variant: bad variant %d", variant);
   h->variant = variant;
   return RDV_OK;
@@ -1030,10 +1268,9 @@ int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth) {
   RDV_CHECK_HANDLE(h);
   if ((tape == nullptr) != (depth <= 0)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_reset_tape: tape and depth must both be set or both be empty");
   h->tape = tape; h->tape_depth = tape ? depth : 0;
+  h->prepared_ok = false;   // the slots hold states of the previous reset source
   return RDV_OK;
 }
-
-static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
 int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream) {
   RDV_CHECK_HANDLE(h);
@@ -1041,11 +1278,12 @@ int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int fresh = (h->fresh && !mask) ? 1 : 0;
   if (h->fresh && mask) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_reset: the first reset after create/seed must cover all envs (mask = NULL)");
-  if (h->storage == RDV_STORAGE_F32)
-    hipLaunchKernelGGL(reset_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
-  else
-    hipLaunchKernelGGL(reset_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, mask, obs_out, h->tape, h->tape_depth, h->seed, h->env_id_offset, fresh);
+  StepArgs A;
+  base_args(h, A);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(reset_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, A, mask, obs_out, fresh);
+  else hipLaunchKernelGGL(reset_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, A, mask, obs_out, fresh);
   RDV_HIP(hipGetLastError());
+  if (fresh) h->prepared_ok = true;   // reset_kernel refills the slot of every env it resets: after a full reset all are current
   h->fresh = false;
   return RDV_OK;
 }
@@ -1060,50 +1298,53 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   if (out->diag && (reinterpret_cast<uintptr_t>(out->diag) & 7)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: diag must be 8-byte aligned");
   DeviceGuard guard(h->device);
   StepArgs A;
-  A.ws = h->ws; A.stats = h->stats; A.actions = actions;
+  base_args(h, A);
+  A.actions = actions;
   A.obs = out->obs; A.reward = out->reward; A.done = out->done; A.terminal_obs = out->terminal_obs;
   A.episode_return = out->episode_return; A.episode_length = out->episode_length; A.done_reason = out->done_reason;
-  A.diag = out->diag; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
-  A.tape_depth = h->tape_depth; A.on_done = h->on_done;
+  A.diag = out->diag;
 #ifdef RDV_STAMPS
   A.stamps = h->stamps;
 #endif
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // general rigid bodies run on the fused layout only (their integrator is a per-lane adaptive loop: no fixed phase to split)
+  // Cold configurations run on the in-lane kernel (step_kernel): evaluator diagnostics, general rigid bodies (their integrator is a
+  // per-lane adaptive loop), the first step after rdv_set_state (kRaw), or when asked for (RDV_VARIANT_INLANE).
   const bool raw = h->raw_state && !h->general;   // (the RK45 kernels integrate the quaternion as given, like the reference)
   h->raw_state = false;
-  const bool split = !h->general && !raw && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
-  const dim3 block(split ? kSplitBlock : kBlock);
-  const dim3 grid = split ? dim3((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)) : grid_for(h->n);
-#define RDV_LAUNCH_STEP(KERNEL)                                                         \
-  do {                                                                                  \
-    if (h->storage == RDV_STORAGE_F32) {                                                \
-      if (A.diag) hipLaunchKernelGGL((KERNEL<float, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);      \
-      else hipLaunchKernelGGL((KERNEL<float, false>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);            \
-    } else {                                                                            \
-      if (A.diag) hipLaunchKernelGGL((KERNEL<double, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);     \
-      else hipLaunchKernelGGL((KERNEL<double, false>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);           \
-    }                                                                                   \
-  } while (0)
-  if (split) RDV_LAUNCH_STEP(step_kernel_split);
-  else if (raw) {
-    if (h->storage == RDV_STORAGE_F32) {
-      if (A.diag) hipLaunchKernelGGL((step_kernel<float, true, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
-      else hipLaunchKernelGGL((step_kernel<float, false, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+  const bool inlane = A.diag || h->general || raw || h->variant == RDV_VARIANT_INLANE;
+#define RDV_LAUNCH(KERNEL, GRID, BLOCK) hipLaunchKernelGGL((KERNEL), GRID, BLOCK, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A)
+  if (!inlane) {
+    if (int rc = ensure_prepared(h, s)) return rc;
+    const bool split = h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs);
+    const bool resets = h->on_done == RDV_ON_DONE_RESET;
+    if (split) {
+      const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
+      if (h->storage == RDV_STORAGE_F32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
+      if (resets) h->tags_clean = false;   // the slots taken in this launch are refilled by the next one
     } else {
-      if (A.diag) hipLaunchKernelGGL((step_kernel<double, true, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
-      else hipLaunchKernelGGL((step_kernel<double, false, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+      if (resets && !h->tags_clean) { if (int rc = refill_marked(h, s)) return rc; }
+      const dim3 grid = grid_for(h->n), block(kBlock);
+      const bool f32 = h->storage == RDV_STORAGE_F32;
+      if (h->fused_min_waves == 4) { if (f32) RDV_LAUNCH((step_kernel_fused<float, 4>), grid, block); else RDV_LAUNCH((step_kernel_fused<double, 4>), grid, block); }
+      else { if (f32) RDV_LAUNCH((step_kernel_fused<float, 3>), grid, block); else RDV_LAUNCH((step_kernel_fused<double, 3>), grid, block); }
+      if (resets) { if (int rc = refill_marked(h, s)) return rc; }
     }
-  }
-  else if (!h->general) RDV_LAUNCH_STEP(step_kernel);
-  else if (h->storage == RDV_STORAGE_F32) {
-    if (A.diag) hipLaunchKernelGGL((step_kernel<float, true, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
-    else hipLaunchKernelGGL((step_kernel<float, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
   } else {
-    if (A.diag) hipLaunchKernelGGL((step_kernel<double, true, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
-    else hipLaunchKernelGGL((step_kernel<double, false, true>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+    const dim3 grid = grid_for(h->n), block(kBlock);
+    const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr;
+    if (h->general) {
+      if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false, true>), grid, block); }
+      else { if (dg) RDV_LAUNCH((step_kernel<double, true, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false, true>), grid, block); }
+    } else if (raw) {
+      if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true, false, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false, false, true>), grid, block); }
+      else { if (dg) RDV_LAUNCH((step_kernel<double, true, false, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false, false, true>), grid, block); }
+    } else {
+      if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false>), grid, block); }
+      else { if (dg) RDV_LAUNCH((step_kernel<double, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false>), grid, block); }
+    }
+    if (h->on_done == RDV_ON_DONE_RESET) h->prepared_ok = false;   // the in-lane kernel resets without the slots: they lag behind now
   }
-#undef RDV_LAUNCH_STEP
+#undef RDV_LAUNCH
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
@@ -1122,15 +1363,18 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if ((h->n & 3) != 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: n_envs must be a multiple of 4 (rows of [K,N,17] / [K,N,6] start 16-byte aligned)");
   DeviceGuard guard(h->device);
   h->raw_state = false;   // the kernel integrates injected (unnormalised) quaternions itself
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (int rc = ensure_prepared(h, s)) return rc;
   StepManyArgs A;
   A.ws = h->ws; A.stats = h->stats; A.actions = actions; A.obs = out->obs; A.reward = out->reward; A.done = out->done;
   A.done_reason = out->done_reason; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
+  A.prep = h->prep; A.prep_obs = h->prep_obs; A.prep_tag = h->prep_tag;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps;
   const dim3 grid((unsigned)((h->n + kManyEnvs - 1) / kManyEnvs)), block(kManyBlock);
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(step_many_kernel<float>, grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
   else hipLaunchKernelGGL(step_many_kernel<double>, grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
   RDV_HIP(hipGetLastError());
+  h->tags_clean = true;   // (as rdv_rollout)
   return RDV_OK;
 }
 
@@ -1155,27 +1399,58 @@ int rdv_get_state(rdv_handle h, double* out, void* stream) {
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_state: null output");
   return access(h, ACC_GET_STATE, nullptr, out, nullptr, stream);
 }
-// ---- snapshot / restore of the whole batch (state, bookkeeping, flags, episode counters, statistics): the chunk arrays and the
-// statistics slots are one contiguous region at the start of the workspace
+// ---- snapshot / restore of the whole batch (state, bookkeeping, flags, episode counters, statistics): a 64-byte header, then
+// the chunk arrays and the statistics slots, which are one contiguous region at the start of the workspace
+struct SnapshotHeader {
+  uint32_t magic, version;
+  int64_t n_envs;
+  int32_t storage, reserved;
+  int64_t payload_bytes;
+  uint64_t pad[4];
+};
+static_assert(sizeof(SnapshotHeader) == 64, "snapshot header layout");
+static constexpr uint32_t kSnapMagic = 0x52445653u;   // "RDVS"
+__global__ void snapshot_header_kernel(const SnapshotHeader hd, SnapshotHeader* dst) { if (threadIdx.x == 0) *dst = hd; }
+static inline int64_t snapshot_payload(const RdvEnvBatch* h) { return chunk_bytes(h->n, h->storage) + stats_bytes(h->n); }
+
 int64_t rdv_snapshot_bytes(rdv_handle h) {
   if (!h || h->magic != kMagic) return -1;
-  return chunk_bytes(h->n, h->storage) + stats_bytes(h->n);
+  return (int64_t)sizeof(SnapshotHeader) + snapshot_payload(h);
 }
 int rdv_snapshot(rdv_handle h, void* dst, void* stream) {
   RDV_CHECK_HANDLE(h);
   if (!dst) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_snapshot: null destination");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_snapshot: nothing to save before the first rdv_reset");
   DeviceGuard guard(h->device);
-  RDV_HIP(hipMemcpyAsync(dst, h->ws, (size_t)rdv_snapshot_bytes(h), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SnapshotHeader hd;
+  std::memset(&hd, 0, sizeof hd);
+  hd.magic = kSnapMagic; hd.version = 1; hd.n_envs = h->n; hd.storage = h->storage; hd.payload_bytes = snapshot_payload(h);
+  hipLaunchKernelGGL(snapshot_header_kernel, dim3(1), dim3(kWave), 0, s, hd, static_cast<SnapshotHeader*>(dst));
+  RDV_HIP(hipGetLastError());
+  RDV_HIP(hipMemcpyAsync(static_cast<char*>(dst) + sizeof(SnapshotHeader), h->ws, (size_t)hd.payload_bytes, hipMemcpyDeviceToDevice, s));
   return RDV_OK;
 }
-int rdv_restore(rdv_handle h, const void* src, void* stream) {
+int rdv_restore(rdv_handle h, const void* src, int64_t src_bytes, void* stream) {
   RDV_CHECK_HANDLE(h);
   if (!src) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: null source");
+  if (src_bytes < (int64_t)sizeof(SnapshotHeader)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: %lld bytes cannot hold a snapshot header", (long long)src_bytes);
   DeviceGuard guard(h->device);
-  RDV_HIP(hipMemcpyAsync(h->ws, src, (size_t)rdv_snapshot_bytes(h), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  SnapshotHeader hd;   // the header is validated on the host: this call synchronises `stream`
+  RDV_HIP(hipMemcpyAsync(&hd, src, sizeof hd, hipMemcpyDeviceToHost, s));
+  RDV_HIP(hipStreamSynchronize(s));
+  if (hd.magic != kSnapMagic || hd.version != 1) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: the buffer does not start with a snapshot header");
+  if (hd.n_envs != h->n || hd.storage != h->storage)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: snapshot of %lld envs with storage %d, this batch has %lld envs with storage %d",
+                (long long)hd.n_envs, hd.storage, (long long)h->n, h->storage);
+  if (hd.payload_bytes != snapshot_payload(h) || src_bytes < (int64_t)sizeof(SnapshotHeader) + hd.payload_bytes)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: the buffer holds %lld bytes, the snapshot needs %lld", (long long)src_bytes,
+                (long long)(sizeof(SnapshotHeader) + snapshot_payload(h)));
+  RDV_HIP(hipMemcpyAsync(h->ws, static_cast<const char*>(src) + sizeof(SnapshotHeader), (size_t)hd.payload_bytes, hipMemcpyDeviceToDevice, s));
   h->fresh = false;
-  h->raw_state = true;   // the snapshot may have been taken right after rdv_set_state
+  h->raw_state = true;      // the snapshot may have been taken right after rdv_set_state
+  h->prepared_ok = false;   // the episode counters changed: the slots are re-derived before the next launch that uses them
   return RDV_OK;
 }
 

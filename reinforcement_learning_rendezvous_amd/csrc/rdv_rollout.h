@@ -13,7 +13,12 @@
 //   - nothing is re-read from HBM between steps and there is no launch boundary: of the 19 us a policy_act + step pair takes
 //     at 65,536 envs, ~5 us are launch gaps and kernel entry/exit, and the state / observation round trips.
 // Phase A (actor waves): obs_t rows -> HBM; the actor of rdv_policy.h (bf16x3 MFMAs, register-resident), noise, clip -> LDS and HBM.
-// Phase B (env waves): transition, reward/done -> HBM, in-lane reset where an episode ended, obs_{t+1} -> LDS.
+// Phase B (env waves): transition, reward/done -> HBM, obs_{t+1} -> LDS.  A lane whose episode ended copies its prepared slot
+// (rdv_slots.h; the workgroup's 256 slots live in LDS during the launch) — no reset arithmetic in the env phase.  The slots taken
+// in a step are refilled during the NEXT actor phase by actor waves 0-3 (one per SIMD; they carry no state between steps, so the
+// refill costs no registers — in the env waves, whose 51 state registers stay live, it spilled), each doing one PART (rc+vc | qc+wc
+// | qt | wt) for the same compacted list of ~13 envs: ~300 fp64 instructions per SIMD and step instead of a ~900-instruction reset
+// in ~96 % of the env waves inside the env phase (round 1: env phase 5.5 us against 2.5 us for the transition alone).
 // (Measured and dropped, all bit-identical in results: (a) preparing every env's next initial state in LDS while the env waves wait
 // for the actor — the vector pipe is the shared resource of both phases, so the fp64 filler work lengthens the actor phase by what
 // it takes off the env phase (13.3 -> 13.6 us per step); (b) actor waves 0-3 doubling as service waves during the env phase, as in
@@ -31,10 +36,14 @@ constexpr int kRollEnvWaves = kRollEnvs / kWave;     // 4
 constexpr int kRollActorWaves = kRollEnvs / kPolWaveEnvs;   // 8
 constexpr int kRollBlock = (kRollEnvWaves + kRollActorWaves) * kWave;   // 768 threads
 // dynamic LDS: actor parameters | unclipped action rows [256][6] (staging) | current observations [256][17] | current (clipped)
-// actions [256][6] | 4 statistics slots
+// actions [256][6] | 4 statistics slots | job kind [256] | job counter [256] | slot chunks [7][256] x (4 ST) | slot observations
+// [5][256] float4 | 4 wave-private job lists [256] u16
 constexpr int kRollLdsFloats = kPolFloats + kRollEnvs * RDV_ACT_DIM + kRollEnvs * RDV_OBS_DIM + kRollEnvs * RDV_ACT_DIM +
-                               kRollEnvWaves * kStatWords * 2;
-constexpr int kRollLdsBytes = kRollLdsFloats * 4;    // 80,096 B
+                               kRollEnvWaves * kStatWords * 2 + 2 * kRollEnvs;
+constexpr int kRollLdsFixed = kRollLdsFloats * 4 + kSlotObsVecs * kRollEnvs * 16 + kRollEnvWaves * kRollEnvs * 2;
+template <typename ST> constexpr int roll_lds_bytes() { return kRollLdsFixed + kChunks * kRollEnvs * 4 * (int)sizeof(ST); }   // 133,344 / 162,016 B
+static_assert(roll_lds_bytes<double>() <= 160 * 1024, "the rollout workgroup must fit the CU's 160 KiB of LDS");
+static_assert(kRollEnvs == kGroupEnvs, "refill_pass_lds is written for 256-env workgroups");
 
 
 struct RolloutArgs {
@@ -47,6 +56,9 @@ struct RolloutArgs {
   float* log_prob;          // nullable [T][N]  log N(a_t; mean, exp(log_std)) summed over the 6 components
   float* last_obs;          // [N][17]  observation after the last step (SB3 _last_obs)
   const double* tape;       // nullable [depth][N][20]
+  void* prep;               // prepared next-episode states in HBM (rdv_slots.h)
+  float4* prep_obs;
+  uint32_t* prep_tag;
   int64_t n;
   uint64_t seed;            // reset RNG (as rdv_step)
   uint64_t env_id_offset;
@@ -68,6 +80,14 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   float* obs_cur = act_raw + kRollEnvs * RDV_ACT_DIM;
   float* act_cur = obs_cur + kRollEnvs * RDV_OBS_DIM;
   uint64_t* stat_lds = reinterpret_cast<uint64_t*>(act_cur + kRollEnvs * RDV_ACT_DIM);   // [4][16]: the rollout's statistics per env wave
+  uint32_t* job_kind = reinterpret_cast<uint32_t*>(stat_lds + kRollEnvWaves * kStatWords);   // [256]
+  uint32_t* job_counter = job_kind + kRollEnvs;                                              // [256]
+  SlotStore<ST> L;                                                                           // the workgroup's slots
+  L.chunks = reinterpret_cast<V*>(job_counter + kRollEnvs);                                  // [7][256]
+  L.obs = reinterpret_cast<float4*>(L.chunks + kChunks * kRollEnvs);                         // [5][256]
+  L.n = kRollEnvs;
+  uint16_t* lists = reinterpret_cast<uint16_t*>(L.obs + kSlotObsVecs * kRollEnvs);           // [4][256]
+  const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform
   const DevParams& P = *Pp;   // scalar loads (see step_kernel)
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
@@ -87,7 +107,11 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   const bool active = env_role && i < n;
   const int64_t env_rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
   Env e;
+  e.episode = 0u;
   bool wt_dirty = false;
+  bool slot_dirty = false;   // this env's slot in LDS differs from the one in HBM
+  SlotStore<ST> H;           // the slots in HBM
+  H.chunks = reinterpret_cast<V*>(A.prep); H.obs = A.prep_obs; H.n = n;
   uint64_t* my_stats = stat_lds + (wv & (kRollEnvWaves - 1)) * kStatWords;
   if (env_role) {
     if (lane < kStatWords) my_stats[lane] = 0ull;
@@ -101,6 +125,14 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
     }
 #pragma unroll
     for (int j = 0; j < RDV_OBS_DIM; ++j) obs_cur[slot * RDV_OBS_DIM + j] = o[j];
+    if (resets) {
+      uint32_t tag = 0u;
+      if (active) { tag = A.prep_tag[i]; slot_copy<ST>(L, slot, H, i); }
+      const bool stale = active && tag != e.episode + 1u;    // left marked by a step_kernel_split launch: refilled before the first use
+      job_kind[slot] = stale ? JOB_REFILL : JOB_NONE;
+      job_counter[slot] = e.episode;
+      slot_dirty = stale;
+    }
   }
   __syncthreads();
 
@@ -118,7 +150,14 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   // Two role-specific loops (so that neither role's registers are live in the other's code); every wave executes exactly
   // two workgroup barriers per step.
   if (!env_role) {
+   const bool refills = resets && a_wave < kGroupWaves;
+   uint16_t* list = lists + (a_wave & (kGroupWaves - 1)) * kRollEnvs;
    for (int t = 0; t < T; ++t) {
+    // the lane id is re-derived every step from an opaque copy: the per-lane addresses of this loop (row stores, LDS fragments,
+    // the refill's job arrays) are then recomputed where they are used (a few integer operations) instead of being hoisted out of the
+    // loop, where they sat in ~40 registers for the whole rollout and spilled to scratch at the 168-VGPR budget of three waves per SIMD
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
     if (a_rows > 0) {
       // ------------------------------------------------------------------ phase A: actor
       const float* xin = obs_cur + r0 * RDV_OBS_DIM;
@@ -127,21 +166,21 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
         if (a_rows == kPolWaveEnvs && vec_rows) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
-            const int q = k * 64 + lane;
+            const int q = k * 64 + ln;
             if (q < kPolWaveEnvs * RDV_OBS_DIM / 4) *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(xin + 4 * q);
           }
         } else {
           const int64_t valid = a_rows * RDV_OBS_DIM;
           for (int j = 0; j < 9; ++j) {
-            const int idx = j * 64 + lane;
+            const int idx = j * 64 + ln;
             if (idx < valid) dst[idx] = xin[idx];
           }
         }
       }
-      const int er = lane & 31, eh = lane >> 5;
+      const int er = ln & 31, eh = ln >> 5;
       float a[4];
-      actor_means(w, xin, lane, a);
-      const float logp = actor_sample(w, lane, A.deterministic, A.noise_seed, A.env_id_offset + (uint64_t)(a_env0 + er),
+      actor_means(w, xin, ln, a);
+      const float logp = actor_sample(w, ln, A.deterministic, A.noise_seed, A.env_id_offset + (uint64_t)(a_env0 + er),
                                       A.noise_counter0 + (uint64_t)t, a);
       // unclipped actions -> staging rows -> HBM; clipped actions -> LDS for the env waves
       if (eh == 0) {
@@ -164,7 +203,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
         const int64_t valid = a_rows * RDV_ACT_DIM;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int idx = k * 128 + lane * 2;
+          const int idx = k * 128 + ln * 2;
           if (idx + 1 < valid) {
             *reinterpret_cast<float2*>(dst + idx) = *reinterpret_cast<const float2*>(araw + idx);
           } else if (idx < valid) {
@@ -174,49 +213,62 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       }
       wave_fence();   // the staging rows are free again before the next step writes them
     }
-    __syncthreads();   // actions of step t are in LDS
+    // actor waves 0-3 (one per SIMD): this wave's part of the slots that were taken in step t-1 (or arrived marked)
+    if (refills) refill_pass_lds<ST>(a_wave, ln, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
+    __syncthreads();   // actions of step t are in LDS; every listed slot has been refilled
     __syncthreads();   // observations of step t+1 are in LDS
    }
+   if (resets) {
+     if (refills) refill_pass_lds<ST>(a_wave, lane, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
+     __syncthreads();   // the slots taken in the last step have been refilled
+   }
   } else {
-   const bool resets = A.on_done == RDV_ON_DONE_RESET;
    for (int t = 0; t < T; ++t) {
-    __syncthreads();   // actions of step t are in LDS
+    __syncthreads();   // actions of step t are in LDS; every listed slot has been refilled
     {
       // ------------------------------------------------------------------ phase B: env transition
+      int sl = slot, ln = lane;   // opaque copies: this loop's per-lane addresses are recomputed, not kept in registers across the rollout
+      asm volatile("" : "+v"(sl), "+v"(ln));
+      const int64_t it = block_base + sl;
       float a[RDV_ACT_DIM];
 #pragma unroll
-      for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[slot * RDV_ACT_DIM + j] : 0.0f;
+      for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[sl * RDV_ACT_DIM + j] : 0.0f;
       StepResult r;
-      const bool stepped = advance<ST, false, false, true>(SA, P, i, active, e, a, r);   // kRaw: a rollout may start from an injected state
+      const bool stepped = advance<ST, false, false, true>(SA, P, it, active, e, a, r);   // kRaw: a rollout may start from an injected state
       const bool fin = stepped && r.done;
       if (active) {
-        A.reward[(int64_t)t * n + i] = r.reward;
-        A.done[(int64_t)t * n + i] = (uint8_t)r.done;
+        A.reward[(int64_t)t * n + it] = r.reward;
+        A.done[(int64_t)t * n + it] = (uint8_t)r.done;
       }
       // episode statistics: the same wavefront reduction as rdv_step (same order of the fp64 sums), into the wave's LDS slot
-      stats_update(my_stats, lane < 12 ? my_stats[lane] : 0ull, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-      if (fin) {
-        if (resets) {
-          const double* row = nullptr;
-          if (A.tape_depth > 0) row = A.tape + ((int64_t)(e.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
-          reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, row);
-          observation(P, e, r.obs);
-          wt_dirty = true;
-        } else if (A.on_done == RDV_ON_DONE_HALT) {
-          e.flags |= FLAG_HALTED;
+      stats_update(my_stats, ln < 12 ? my_stats[ln] : 0ull, ln, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+      if (resets) {
+        if (fin) {
+          SlotRaw<ST> raw;
+          slot_fetch<ST>(L, sl, raw);
+          slot_unpack<ST>(P, raw, e, r.obs);      // SB3: the first obs of the next episode
+          slot_dirty = true; wt_dirty = true;
         }
+        job_kind[sl] = fin ? JOB_REFILL : JOB_NONE;   // read by the refilling waves after the next barrier
+        job_counter[sl] = e.episode;
+      } else if (fin && A.on_done == RDV_ON_DONE_HALT) {
+        e.flags |= FLAG_HALTED;
       }
 #pragma unroll
-      for (int j = 0; j < RDV_OBS_DIM; ++j) obs_cur[slot * RDV_OBS_DIM + j] = r.obs[j];
+      for (int j = 0; j < RDV_OBS_DIM; ++j) obs_cur[sl * RDV_OBS_DIM + j] = r.obs[j];
     }
     __syncthreads();   // observations of step t+1 are in LDS
    }
-  }
-
-  if (env_role) {
-    // ---- the observation after the last step, the state and the statistics go back to HBM
+   if (resets) __syncthreads();   // the slots taken in the last step have been refilled (actor waves)
+   // (the epilogue lives inside the env branch: after the join the env state would count as live across the actor loop too, and
+   //  its 51 registers would be saved to scratch around it)
+    // ---- the observation after the last step, the state, the slots that changed and the statistics go back to HBM
     store_obs_rows(A.last_obs, wave_base, env_rows, lane, obs_cur + (slot - lane) * RDV_OBS_DIM);
     if (active) store_env<ST>(reinterpret_cast<V*>(A.ws), n, i, e, wt_dirty);
+    if (active && slot_dirty) {
+      slot_copy<ST>(H, i, L, slot);
+      A.prep_tag[i] = e.episode + 1u;
+    }
     if (env_rows > 0 && lane < 12) {   // this wave's statistics slot in HBM += the rollout's (counters as integers, sums as fp64)
       uint64_t* slot_stats = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
       const uint64_t pre = slot_stats[lane], add = my_stats[lane];

@@ -1,25 +1,30 @@
 // rdv_step_many.h — K env steps in ONE persistent launch for an OPEN-LOOP action tape actions[K][N][6] (random-action
 // workloads, replaying recorded actions): rdv_step called K times, without the launch boundaries and without the state's round
 // trips through HBM.  Not the closed loop (that is rdv_rollout, with the actor in the loop) and not the shape the headline
-// metric is quoted on (one launch per timestep, rdv_step); it shows what those boundaries cost: ~7.8 us per step -> ~4 us.
+// metric is quoted on (one launch per timestep, rdv_step); it shows what those boundaries cost.
 //
 // Included by rdv_hip.hip after the step helpers.  Same arithmetic as rdv_step (the tests require bit-identical outputs, state
-// and statistics).  A 512-thread workgroup owns 256 envs for all K steps, split-role as step_kernel_split:
+// and statistics).  A 512-thread workgroup owns 256 envs for all K steps:
 //   - waves 0-3 ("env waves", 64 envs each) keep the state in registers and do the transition; the actions of step t+1 are
-//     fetched into registers while step t computes;
-//   - waves 4-7 ("service waves", on the same SIMDs) compute every env's next initial state + observation beside each step and
-//     hand it over through LDS where an episode ended (two workgroup barriers per step), so the reset is never on the env waves'
-//     critical path.
+//     fetched into registers while step t computes.  A lane whose episode ends copies its prepared slot (rdv_slots.h) — the
+//     workgroup's 256 slots live in LDS for the duration of the launch;
+//   - waves 4-7 ("service waves", one per SIMD beside an env wave) refill the slots used in the previous step, sharing the work by
+//     PART (rc+vc | qc+wc | qt | wt) over the same compacted list: ~13 of 256 envs per step with random actions, a ~300-instruction
+//     stream per SIMD and step where round 1 ran the whole ~900-instruction reset for every lane.
+// Two workgroup barriers per step: A (refills of the previous step are in LDS; the transition of this step is done) and B (the
+// slots that were taken are listed).  At the end the slots that changed go back to HBM, clean.
 #pragma once
 
 namespace rdv {
 
-constexpr int kManyEnvs = 256;
+constexpr int kManyEnvs = kGroupEnvs;         // 256
 constexpr int kManyEnvWaves = kManyEnvs / kWave;   // 4
 constexpr int kManyBlock = 2 * kManyEnvs;          // 512 threads: 4 env waves + 4 service waves
-// dynamic LDS: observation rows [256][17] | action rows [256][6] | finished flags [256] | 4 statistics slots | next states [7][256] x (4 ST)
-constexpr int kManyLdsFixed = (kManyEnvs * RDV_OBS_DIM + kManyEnvs * RDV_ACT_DIM + kManyEnvs) * 4 + kManyEnvWaves * kStatWords * 8;
-template <typename ST> constexpr int many_lds_bytes() { return kManyLdsFixed + kChunks * kManyEnvs * 4 * (int)sizeof(ST); }   // 53,760 / 82,432 B
+// dynamic LDS: observation rows [256][17] | action rows [256][6] | job kind [256] | job counter [256] | 4 statistics slots |
+// slot chunks [7][256] x (4 ST) | slot observations [5][256] float4 | 4 wave-private job lists [256] u16
+constexpr int kManyLdsFixed = (kManyEnvs * RDV_OBS_DIM + kManyEnvs * RDV_ACT_DIM + 2 * kManyEnvs) * 4 + kManyEnvWaves * kStatWords * 8 +
+                              kSlotObsVecs * kManyEnvs * 16 + kManyEnvWaves * kManyEnvs * 2;
+template <typename ST> constexpr int many_lds_bytes() { return kManyLdsFixed + kChunks * kManyEnvs * 4 * (int)sizeof(ST); }   // 77,312 / 105,984 B
 
 struct StepManyArgs {
   void* ws;                 // chunk arrays (state in, state out)
@@ -30,6 +35,9 @@ struct StepManyArgs {
   uint8_t* done;            // [K][N]
   uint8_t* done_reason;     // nullable [K][N]
   const double* tape;       // nullable [depth][N][20]
+  void* prep;               // prepared next-episode states in HBM (rdv_slots.h)
+  float4* prep_obs;
+  uint32_t* prep_tag;
   int64_t n;
   uint64_t seed;
   uint64_t env_id_offset;
@@ -44,21 +52,27 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* obs_rows = lds;                                                           // [256][17]
   float* act_rows = obs_rows + kManyEnvs * RDV_OBS_DIM;                            // [256][6]
-  uint32_t* fin_flag = reinterpret_cast<uint32_t*>(act_rows + kManyEnvs * RDV_ACT_DIM);   // [256]
-  uint64_t* stat_lds = reinterpret_cast<uint64_t*>(fin_flag + kManyEnvs);          // [4][16]
-  V* nxt = reinterpret_cast<V*>(stat_lds + kManyEnvWaves * kStatWords);            // [7][256]
+  uint32_t* job_kind = reinterpret_cast<uint32_t*>(act_rows + kManyEnvs * RDV_ACT_DIM);   // [256]
+  uint32_t* job_counter = job_kind + kManyEnvs;                                    // [256]
+  uint64_t* stat_lds = reinterpret_cast<uint64_t*>(job_counter + kManyEnvs);       // [4][16]
+  SlotStore<ST> L;                                                                 // the workgroup's slots
+  L.chunks = reinterpret_cast<V*>(stat_lds + kManyEnvWaves * kStatWords);          // [7][256]
+  L.obs = reinterpret_cast<float4*>(L.chunks + kChunks * kManyEnvs);               // [5][256]
+  L.n = kManyEnvs;
+  uint16_t* lists = reinterpret_cast<uint16_t*>(L.obs + kSlotObsVecs * kManyEnvs); // [4][256]
   const DevParams& P = *Pp;   // scalar loads (see step_kernel)
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
   const bool env_role = wv < kManyEnvWaves;
-  const int slot = (wv & (kManyEnvWaves - 1)) * kWave + lane;    // both roles: the env this lane is responsible for
+  const int slot = (wv & (kManyEnvWaves - 1)) * kWave + lane;    // env waves: the env this lane is responsible for
   const int64_t n = A.n;
-  const int64_t i = (int64_t)blockIdx.x * kManyEnvs + slot;
+  const int64_t block_base = (int64_t)blockIdx.x * kManyEnvs;
+  const int64_t i = block_base + slot;
   const int64_t wave_base = i - lane;
   const bool active = i < n;
   const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
   const int K = A.n_steps;
-  const bool resets = A.on_done == RDV_ON_DONE_RESET;
+  const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform: the barriers below are executed by all waves or by none
   V* ws = reinterpret_cast<V*>(A.ws);
 
   if (env_role) {
@@ -68,9 +82,21 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     float* my_act = act_rows + (slot - lane) * RDV_ACT_DIM;
     uint64_t* my_stats = stat_lds + wv * kStatWords;
     if (lane < kStatWords) my_stats[lane] = 0ull;
+    SlotStore<ST> H;   // the slots in HBM
+    H.chunks = reinterpret_cast<V*>(A.prep); H.obs = A.prep_obs; H.n = n;
     Env e;
+    e.episode = 0u;
+    bool slot_dirty = false;   // this env's slot in LDS differs from the one in HBM
     bool wt_dirty = false;
     if (active) load_env<ST>(ws, n, i, e);
+    if (resets) {
+      uint32_t tag = 0u;
+      if (active) { tag = A.prep_tag[i]; slot_copy<ST>(L, slot, H, i); }
+      const bool stale = active && tag != e.episode + 1u;    // left marked by a step_kernel_split launch: refilled before the first use
+      job_kind[slot] = stale ? JOB_REFILL : JOB_NONE;
+      job_counter[slot] = e.episode;
+      slot_dirty = stale;
+    }
     StepArgs SA;
     SA.diag = nullptr;
     // the wave's action rows [64][6] of one step are 384 contiguous floats: 3 x float2 per lane
@@ -87,6 +113,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     };
     float2 pre[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
     if (rows > 0) fetch(0, pre);
+    if (resets) __syncthreads();   // S0: the slots and the entry jobs are in LDS
     for (int k = 0; k < K; ++k) {
       // actions of this step: registers -> LDS rows -> own row; then request the next step's while this one computes
 #pragma unroll
@@ -108,19 +135,33 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
       }
       stats_update(my_stats, lane < 12 ? my_stats[lane] : 0ull, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
       if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-      fin_flag[slot] = (fin && resets) ? 1u : 0u;
+      if (resets) {
+        const bool take = fin;
+        __syncthreads();   // A: every slot listed earlier has been refilled
+        if (take) {
+          SlotRaw<ST> raw;
+          slot_fetch<ST>(L, slot, raw);
+          slot_unpack<ST>(P, raw, e, r.obs);      // SB3: the first obs of the next episode
+          slot_dirty = true; wt_dirty = true;
+        }
+        job_kind[slot] = take ? JOB_REFILL : JOB_NONE;
+        job_counter[slot] = e.episode;
+        __syncthreads();   // B: the slots taken in this step are listed
+      }
 #pragma unroll
       for (int j = 0; j < RDV_OBS_DIM; ++j) my_obs[lane * RDV_OBS_DIM + j] = r.obs[j];
-      __syncthreads();   // the service waves see the finished-episode flags and may replace rows / hand states over
-      __syncthreads();   // ... done
-      if (fin && resets) {
-        load_env<ST>(nxt, kManyEnvs, slot, e);
-        wt_dirty = true;
-      }
+      wave_lds_fence();
       store_obs_rows(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs);
       wave_lds_fence();   // the rows are rewritten by the next step
     }
     if (active) store_env<ST>(ws, n, i, e, wt_dirty);
+    if (resets) {
+      __syncthreads();   // F: the slots taken in the last step have been refilled
+      if (active && slot_dirty) {
+        slot_copy<ST>(H, i, L, slot);
+        A.prep_tag[i] = e.episode + 1u;
+      }
+    }
     if (rows > 0 && lane < 12) {   // this wave's statistics slot in HBM += the launch's (counters as integers, sums as fp64)
       uint64_t* slot_stats = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
       const uint64_t pre_s = slot_stats[lane], add = my_stats[lane];
@@ -128,36 +169,18 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
       const uint64_t as_real = (uint64_t)__double_as_longlong(__longlong_as_double((long long)pre_s) + __longlong_as_double((long long)add));
       slot_stats[lane] = lane <= ST_SUM_LEN ? as_int : as_real;
     }
-  } else {
+  } else if (resets) {
     // ------------------------------------------------------------------ service waves
-    const bool s_active = active && resets;
-    uint32_t episode = 0;
-    if (s_active) episode = s2u(ws[5 * n + i].w);
-    V packed[kChunks];
-    float robs[RDV_OBS_DIM];
-    bool have = false;   // the prepared state depends only on (seed, env id, episode): it stays valid until it is used
+    const int role = wv - kManyEnvWaves;
+    uint16_t* list = lists + role * kManyEnvs;
+    __syncthreads();   // S0
     for (int k = 0; k < K; ++k) {
-      if (s_active && !have) {
-        Env ne;
-        ne.episode = episode;
-        const double* row = nullptr;
-        if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
-        reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
-        reset_aux<ST>(P, ne);
-        observation(P, ne, robs);
-        pack_env<ST>(ne, packed);
-        have = true;
-      }
-      __syncthreads();   // the transition of step k is done
-      if (s_active && fin_flag[slot] != 0u) {
-        have = false;
-        store_chunks<ST>(nxt, kManyEnvs, slot, packed, true);
-#pragma unroll
-        for (int j = 0; j < RDV_OBS_DIM; ++j) obs_rows[slot * RDV_OBS_DIM + j] = robs[j];   // SB3: the first obs of the next episode
-        episode += 1u;
-      }
-      __syncthreads();
+      refill_pass_lds<ST>(role, lane, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
+      __syncthreads();   // A
+      __syncthreads();   // B
     }
+    refill_pass_lds<ST>(role, lane, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
+    __syncthreads();   // F
   }
 }
 

@@ -24,7 +24,8 @@ class MlpPolicy(torch.nn.Module):
         super().__init__()
         self.backend = backend          # "auto": HIP kernel for CUDA observations, PyTorch otherwise; "torch"; "hip"
         self.noise_seed = int(seed)     # HIP backend: Philox key of the exploration noise; the call counter is the step index
-        self.noise_env_offset = 0       # HIP backend: global index of row 0 (sharded batches: noise keyed by global env id)
+        self.noise_env_offset = 0       # HIP backend: global index of row 0 when act() is not told (sharded batches key the noise by
+                                        # GLOBAL env id: RendezvousBatch.act / .rollout pass the shard's env_id_offset themselves)
         self._hip = {}                  # device index -> rdv_policy handle
         self._hip_critic = {}           # device index -> rdv_policy handle of the critic
         self._calls = 0
@@ -86,8 +87,9 @@ class MlpPolicy(torch.nn.Module):
             self._hip[idx] = h
         return self._hip[idx]
 
-    def _act_hip(self, obs, deterministic, out=None):
+    def _act_hip(self, obs, deterministic, out=None, env_id_offset=None):
         from . import _native as N
+        offset = self.noise_env_offset if env_id_offset is None else int(env_id_offset)
         obs = obs.contiguous()
         n = obs.shape[0]
         if out is None:
@@ -95,7 +97,7 @@ class MlpPolicy(torch.nn.Module):
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
         N.check(N.lib().rdv_policy_act(self._hip_handle(obs.device), C.c_void_p(obs.data_ptr()), C.c_void_p(out.data_ptr()), n,
                                        int(bool(deterministic)), C.c_uint64(self.noise_seed), C.c_uint64(self._calls),
-                                       C.c_uint64(self.noise_env_offset), stream))
+                                       C.c_uint64(offset), stream))
         self._calls += 1
         return out
 
@@ -131,14 +133,15 @@ class MlpPolicy(torch.nn.Module):
             self._hip, self._hip_critic = {}, {}
 
     @torch.no_grad()
-    def act(self, obs, deterministic=True, generator=None, out=None):
-        """SB3 ``predict``: the distribution mean (or a sample), clipped to the action Box."""
+    def act(self, obs, deterministic=True, generator=None, out=None, env_id_offset=None):
+        """SB3 ``predict``: the distribution mean (or a sample), clipped to the action Box.  HIP backend: the exploration noise of
+        row i is keyed by (noise_seed, env_id_offset + i, call counter); ``env_id_offset`` defaults to ``noise_env_offset``."""
         hip = self.backend == "hip" or (self.backend == "auto" and obs.is_cuda and obs.dtype == torch.float32
                                         and obs.dim() == 2 and obs.shape[1] == 17)
         if hip:
             if generator is not None:
                 self.noise_seed = int(generator.initial_seed())
-            return self._act_hip(obs, deterministic, out)
+            return self._act_hip(obs, deterministic, out, env_id_offset)
         a = self.mean(obs)
         if not deterministic:
             noise = torch.randn(a.shape, dtype=a.dtype, device=a.device, generator=generator)
