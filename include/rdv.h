@@ -67,6 +67,7 @@ typedef enum RdvKernelVariant {
   RDV_VARIANT_AUTO = 0,
   RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs; one wave per 512 envs refills the slots that were used */
   RDV_VARIANT_SPLIT = 2,  /* step waves + service waves that refill the slots of the previous launch beside them, by part */
+  RDV_VARIANT_SPLIT_R1 = 4, /* (experimental) round 1's split kernel */
   RDV_VARIANT_INLANE = 3  /* round 1's layout: resets computed divergently in the lane whose episode ended (the kernel of the
                              evaluator-diagnostics / rigid-body / first-step-after-set_state configurations; a reference for the others) */
 } RdvKernelVariant;

@@ -18,7 +18,7 @@ from .params import EnvParams, make_params
 
 _STORAGE = {"f32": N.STORAGE_F32, "f64": N.STORAGE_F64, N.STORAGE_F32: N.STORAGE_F32, N.STORAGE_F64: N.STORAGE_F64}
 _ON_DONE = {"reset": N.ON_DONE_RESET, "halt": N.ON_DONE_HALT, "continue": N.ON_DONE_CONTINUE}
-_VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT, "inlane": N.VARIANT_INLANE}
+_VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT, "inlane": N.VARIANT_INLANE, "split_r1": 4}
 
 
 class RendezvousBatch:

@@ -337,24 +337,30 @@ __device__ __forceinline__ void integrate_attitude_rk45(double* q, double* w, co
 }
 
 // Flags/reward inputs from the canonical state: one R(qc), one R(qt) per call (the reference rebuilds them ~10x per step).
+// Two halves, so that the step can finish the chaser side first and have the attitude error's table entry (attitude_error_of)
+// travelling while the target side computes:
+//   derive_chaser : R(qc), |rc|, k_att                      derive_target : R(qt), position error, and the lazy terms
 // kLazy (training kernels): the velocity / rotation-rate errors are only ever compared after the position error has
 // passed its limit (:417 np.all, :348), and the corridor angle only inside the KOZ sphere (:397); far from the target
 // they are skipped and set to +inf, which fails exactly the comparisons the reference would fail.
-template <bool kLazy>
-__device__ __forceinline__ void derive(const DevParams& P, const Env& e, Derived& d) {
-  double Rc[9], Rt[9];
+__device__ __forceinline__ void derive_chaser(const DevParams& P, const Env& e, Derived& d, double* Rc, double& inv_dist) {
   quat2mat(e.qc, Rc);
-  quat2mat(e.qt, Rt);
-  double cap_l[3], rd_l[3];
+  double cap_l[3];
   matvec(Rc, P.capture_axis, cap_l);    // :431
-  matvec(Rt, P.rd, rd_l);               // :460
-  const double dp[3] = {e.rc[0] - rd_l[0], e.rc[1] - rd_l[1], e.rc[2] - rd_l[2]};
   const double r2 = dot3(e.rc, e.rc);
-  const double inv_dist = rsqrt64(r2);
+  inv_dist = rsqrt64(r2);
   d.dist = r2 * inv_dist;
-  d.pos2 = dot3(dp, dp);                // :463
   // general.py:179: round(cos, 5) == rint(cos*1e5)/1e5; rotations preserve |capture_axis|, |corridor_axis|
   d.k_att = rint(-dot3(e.rc, cap_l) * (inv_dist * P.inv_capture_norm) * 1e5);           // :432
+}
+template <bool kLazy>
+__device__ __forceinline__ void derive_target(const DevParams& P, const Env& e, Derived& d, const double* Rc, double inv_dist) {
+  double Rt[9];
+  quat2mat(e.qt, Rt);
+  double rd_l[3];
+  matvec(Rt, P.rd, rd_l);               // :460
+  const double dp[3] = {e.rc[0] - rd_l[0], e.rc[1] - rd_l[1], e.rc[2] - rd_l[2]};
+  d.pos2 = dot3(dp, dp);                // :463
   const double inf = __builtin_huge_val();
   d.vel2 = inf; d.rot2 = inf; d.k_corr = inf;
   if (!kLazy || d.pos2 <= P.max_rd_error2) {
@@ -373,6 +379,12 @@ __device__ __forceinline__ void derive(const DevParams& P, const Env& e, Derived
     matvec(Rt, P.corridor_axis, corr_l);                                                // :400
     d.k_corr = rint(dot3(e.rc, corr_l) * (inv_dist * P.inv_corridor_norm) * 1e5);
   }
+}
+template <bool kLazy>
+__device__ __forceinline__ void derive(const DevParams& P, const Env& e, Derived& d) {
+  double Rc[9], inv_dist;
+  derive_chaser(P, e, d, Rc, inv_dist);
+  derive_target<kLazy>(P, e, d, Rc, inv_dist);
 }
 
 // k / 1e5 correctly rounded (k is an integer-valued double, |k| <= 1e5): product by 1e-5 plus one residual correction
@@ -656,21 +668,32 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   // :173, :180 delta_w = a[3:] * max_delta_w is a float64 product (max_delta_w is np.float64)
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = fma((double)a[3 + i], P.max_delta_w, e.wc[i]);
-  if (kGeneral) {   // general inertia / torque: the reference's own integrator (both rates evolve)
-    integrate_attitude_rk45(e.qc, e.wc, P.body_inertia[0], P.body_inv_inertia[0], P.body_torque[0], P.dt, P.rk_rtol, P.rk_atol);   // :181
-    integrate_attitude_rk45(e.qt, e.wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);   // :184
-#pragma unroll
-    for (int i = 0; i < 3; ++i) e.wt[i] = canon(e.wt[i], tag);
-  } else {
-    integrate_attitude<kRaw>(e.qc, e.wc, P.half_dt);   // :181
-    integrate_attitude<kRaw>(e.qt, e.wt, P.half_dt);   // :184
-  }
+  // Chaser side first (:181), then its half of the derived quantities: the attitude error's table entry (the one dependent memory
+  // access of a transition) is requested here and is needed ~500 instructions later, for the reward.
+  if (kGeneral) integrate_attitude_rk45(e.qc, e.wc, P.body_inertia[0], P.body_inv_inertia[0], P.body_torque[0], P.dt, P.rk_rtol, P.rk_atol);   // general inertia / torque: the reference's own integrator (both rates evolve)
+  else integrate_attitude<kRaw>(e.qc, e.wc, P.half_dt);
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = canon(e.wc[i], tag);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { e.qc[i] = canon(e.qc[i], tag); e.qt[i] = canon(e.qt[i], tag); }
-
-  derive<kLazy>(P, e, d);
+  for (int i = 0; i < 4; ++i) e.qc[i] = canon(e.qc[i], tag);
+  double Rc[9], inv_dist;
+  derive_chaser(P, e, d, Rc, inv_dist);
+#ifdef RDV_ABL_NOACOS
+  const double att = 0.1 + 1e-9 * d.k_att;
+#else
+  const double att = attitude_error_of(P, d.k_att);
+#endif
+  // target side (:184)
+  if (kGeneral) {
+    integrate_attitude_rk45(e.qt, e.wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e.wt[i] = canon(e.wt[i], tag);
+  } else {
+    integrate_attitude<kRaw>(e.qt, e.wt, P.half_dt);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e.qt[i] = canon(e.qt[i], tag);
+  derive_target<kLazy>(P, e, d, Rc, inv_dist);
   const bool inst_coll = in_koz(P, d);
   // :187-190
   if (!(e.flags & FLAG_COLLIDED)) {
@@ -694,7 +717,6 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
   r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
   // :313-353
-  const double att = attitude_error_of(P, d.k_att);
   double rew = P.att_term * fma(-att, P.inv_max_attitude_error, 1.0);                  // :329
   rew += (double)(mul_f32_rn(P.fuel_scale_f32, sum_v) / P.fuel_div_f32);               // :333
   if (inst_coll) rew -= P.coll_term;                                                   // :336-337

@@ -125,8 +125,7 @@ struct StepArgs {
   uint64_t env_id_offset;
   int32_t tape_depth;
   int32_t on_done;
-  void* prep;               // prepared next-episode states (csrc/rdv_slots.h): chunk arrays [7][N]
-  float4* prep_obs;         // their observations [5][N]
+  void* prep;               // prepared next-episode states (csrc/rdv_slots.h): one record per env
   uint32_t* prep_tag;       // [N]
 #ifdef RDV_STAMPS
   unsigned long long* stamps;
@@ -183,19 +182,48 @@ __device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t 
   }
 }
 
-// Episode statistics of one wave of envs, as wavefront reductions: ballot + popcount for the counters; the sums run over
-// the finished lanes only (they are sparse: ~1-5 % of envs end per step), picked out of the ballot mask in ascending lane
-// order with v_readlane — a fixed order, so the fp64 sums are reproducible.  Lanes 0..11 then write the wave's private
-// 128-byte slot; `pre` is that slot's previous content, loaded by lanes 0..11 at kernel entry so that no memory
-// latency is paid here.
 __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
   return __hiloint2double(hi, lo);
 }
+// Wave-wide sums by DPP (no LDS, no loop): four row_shr steps inside each row of 16 lanes, then row_bcast:15 / :31 carry the row
+// totals upwards; lane 63 ends with the sum of all 64 lanes.  A fixed tree: the fp64 sums are reproducible run to run and the same
+// in every kernel (they all reduce through here).  Round 1 walked the finished lanes with v_readlane in a scalar loop — serial,
+// ~0.7 us of the step wave at 65,536 envs (ablation: profiles/r02_ablation_split.txt).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ int dpp_shift_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xf, false); }
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ double dpp_step_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
+  return v + __hiloint2double(hi, lo);      // lanes outside the row mask / without a source lane add +0.0
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v = dpp_step_f64<0x111, 0xf>(v);   // row_shr:1
+  v = dpp_step_f64<0x112, 0xf>(v);   // row_shr:2
+  v = dpp_step_f64<0x114, 0xf>(v);   // row_shr:4
+  v = dpp_step_f64<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row's sum
+  v = dpp_step_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+  v = dpp_step_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
+  return readlane_f64(v, 63);
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += dpp_shift_i32<0x111, 0xf>(v);
+  v += dpp_shift_i32<0x112, 0xf>(v);
+  v += dpp_shift_i32<0x114, 0xf>(v);
+  v += dpp_shift_i32<0x118, 0xf>(v);
+  v += dpp_shift_i32<0x142, 0xa>(v);
+  v += dpp_shift_i32<0x143, 0xc>(v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
 __device__ __forceinline__ uint64_t stats_preload(const uint64_t* __restrict__ slot, int lane) {
   return lane < 12 ? slot[lane] : 0ull;
 }
+// Episode statistics of one wave of envs, as wavefront reductions: ballot + popcount for the counters, DPP sums over the finished
+// lanes (the others contribute zero) for episode length, return and the two delta-v totals.  Lanes 0..11 then write the wave's
+// private 128-byte slot; `pre` is that slot's previous content, loaded by lanes 0..11 at kernel entry so that no memory latency
+// is paid here.
 __device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, uint64_t pre, int lane, bool stepped, bool fin,
                                              int reason, uint32_t flags, int k, double ep_ret, double sum_dv, double sum_dw) {
   const unsigned long long m_step = __ballot(stepped);
@@ -206,15 +234,10 @@ __device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, uint64
     const unsigned long long m_coll = __ballot(fin && (flags & FLAG_COLLIDED));
     const unsigned long long m_r1 = __ballot(fin && reason == 1), m_r2 = __ballot(fin && reason == 2);
     const unsigned long long m_r3 = __ballot(fin && reason == 3), m_r4 = __ballot(fin && reason == 4);
-    int s_len = 0;
-    double s_ret = 0.0, s_dv = 0.0, s_dw = 0.0;
-    for (unsigned long long m = m_fin; m != 0ull; m &= m - 1ull) {   // scalar loop over the finished lanes
-      const int src = __builtin_ctzll(m);
-      s_len += __builtin_amdgcn_readlane(k, src);
-      s_ret += readlane_f64(ep_ret, src);
-      s_dv += readlane_f64(sum_dv, src);
-      s_dw += readlane_f64(sum_dw, src);
-    }
+    const int s_len = wave_sum_i32(fin ? k : 0);
+    const double s_ret = wave_sum_f64(fin ? ep_ret : 0.0);
+    const double s_dv = wave_sum_f64(fin ? sum_dv : 0.0);
+    const double s_dw = wave_sum_f64(fin ? sum_dw : 0.0);
     if (lane < 12) {
       // straight-line selects (a switch on the lane id compiles to a tree of exec-masked branches)
       uint32_t iv = (uint32_t)__popcll(m_step);
@@ -355,21 +378,33 @@ namespace rdv {
 
 // ---------------------------------------------------------------------------------------------------------------
 // Fused variant (the chip is full: several waves per SIMD, N > ~98k envs): every wave does the whole transition for its 64 envs.
-// A lane whose episode ends copies its prepared slot (rdv_slots.h) and marks it — no reset arithmetic, no barrier, no second role
-// in the step path.  The marked slots are refilled by refill_kernel, launched right behind on the same stream: it finds them by
-// their tags and runs the reset DENSELY (one wave compacts the marks of 1,024 envs: ~51 per step with random actions, one pass at
-// ~80 % lane use), i.e. the reset costs ~5 % of a step's instructions instead of the ~40 % of the divergent in-lane form.
+// A lane whose episode ends only MARKS its prepared slot (rdv_slots.h): no reset arithmetic, no barrier, no second role and no
+// dependent memory access in the step path, which is then a pure stream — what it costs otherwise: with the slot copied in the
+// step wave (12 sparse loads, waited for in ~96 % of the waves) the kernel took as long as with the in-lane reset, 59 % of its
+// wave-cycles parked on s_waitcnt (profiles/r02_sq_counters_4M.csv).  refill_kernel, launched right behind on the same stream, finds
+// the marked slots by their tags (one wave compacts the marks of 1,024 envs: ~51 per step with random actions), copies each into its
+// env (state, first observation of the new episode) and runs the reset for the following episode DENSELY, one pass at ~80 % lane use:
+// the reset costs ~5 % of a step's instructions instead of the ~40 % of the divergent in-lane form.
 // kMinWaves: waves per SIMD the register allocation is held to (256-thread workgroups: 3 -> 168 VGPRs, 4 -> 128).
 template <typename ST>
-__device__ __forceinline__ SlotStore<ST> hbm_slots(const StepArgs& A) {
-  SlotStore<ST> S;
-  S.chunks = reinterpret_cast<typename Vec4<ST>::type*>(A.prep); S.obs = A.prep_obs; S.n = A.n;
-  return S;
-}
+__device__ __forceinline__ SlotStore<ST> hbm_slots(const StepArgs& A) { return hbm_slot_store<ST>(A.prep); }
 
 // The whole reset of episode `counter` into env i's slot (one lane per env): refill_kernel, prepare_kernel, reset_kernel.
+// take: the env first continues from what the slot holds (auto-reset, SB3 DummyVecEnv semantics: its state, and the first
+// observation of the new episode as the step's returned observation).
 template <typename ST>
-__device__ __forceinline__ void refill_whole(const StepArgs& A, const DevParams& P, int64_t i, uint32_t counter) {
+__device__ __forceinline__ void refill_whole(const StepArgs& A, const DevParams& P, int64_t i, uint32_t counter, bool take = false) {
+  if (take) {
+    SlotRaw<ST> raw;
+    slot_fetch<ST>(hbm_slots<ST>(A), i, raw);
+    Env cont;
+    float co[RDV_OBS_DIM];
+    slot_unpack<ST>(P, raw, cont, co);
+    store_env<ST>(reinterpret_cast<typename Vec4<ST>::type*>(A.ws), A.n, i, cont, true);
+    float* row = A.obs + i * RDV_OBS_DIM;
+#pragma unroll
+    for (int j = 0; j < RDV_OBS_DIM; ++j) row[j] = co[j];
+  }
   Env ne;
   float o[RDV_OBS_DIM];
   reset_whole<ST>(P, ne, o, A.seed, A.env_id_offset + (uint64_t)i, counter, tape_row_of(A.tape, A.tape_depth, A.n, i, counter));
@@ -377,52 +412,127 @@ __device__ __forceinline__ void refill_whole(const StepArgs& A, const DevParams&
   A.prep_tag[i] = counter + 1u;
 }
 
-template <typename ST, int kMinWaves>
+// The inputs of one tile of 64 envs, as requested from memory (nothing waits for them here): the seven state chunks, the wave's
+// action rows [64][6] (3 x float2 per lane, transposed through LDS when they are used) and the wave's statistics slot.
+template <typename ST>
+struct TileIn {
+  typename Vec4<ST>::type c[kChunks];
+  float2 act[3];
+  uint64_t stat;
+};
+template <typename ST>
+__device__ __forceinline__ void tile_request(const StepArgs& A, int64_t wave_base, int lane, TileIn<ST>& in) {
+  using V = typename Vec4<ST>::type;
+  const int64_t n = A.n, i = wave_base + lane;
+  const V* ws = reinterpret_cast<const V*>(A.ws);
+  if (i < n) {
+#pragma unroll
+    for (int k = 0; k < kChunks; ++k) in.c[k] = ws[k * n + i];
+  }
+  const int64_t valid = ((n - wave_base) < kWave ? (n - wave_base) : kWave) * RDV_ACT_DIM;
+  const float* src = A.actions + wave_base * RDV_ACT_DIM;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int idx = q * 128 + lane * 2;
+    in.act[q] = make_float2(0.0f, 0.0f);
+    if (idx + 1 < valid) in.act[q] = *reinterpret_cast<const float2*>(src + idx);
+    else if (idx < valid) in.act[q].x = src[idx];
+  }
+  in.stat = valid > 0 ? stats_preload(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, lane) : 0ull;
+}
+template <typename ST>
+__device__ __forceinline__ void unpack_chunks(const typename Vec4<ST>::type* c, Env& e) {
+  e.rc[0] = c[0].x; e.rc[1] = c[0].y; e.rc[2] = c[0].z; e.vc[0] = c[0].w;
+  e.vc[1] = c[1].x; e.vc[2] = c[1].y; e.wc[0] = c[1].z; e.wc[1] = c[1].w;
+  e.wc[2] = c[2].x; e.bubble = c[2].y; e.sum_dv = c[2].z; e.sum_dw = c[2].w;
+  e.qc[0] = c[3].x; e.qc[1] = c[3].y; e.qc[2] = c[3].z; e.qc[3] = c[3].w;
+  e.qt[0] = c[4].x; e.qt[1] = c[4].y; e.qt[2] = c[4].z; e.qt[3] = c[4].w;
+  e.ep_ret = c[5].x; e.k = (int32_t)s2u(c[5].y); e.flags = s2u(c[5].z); e.episode = s2u(c[5].w);
+  e.wt[0] = c[6].x; e.wt[1] = c[6].y; e.wt[2] = c[6].z;
+}
+
+// One tile: transition, statistics, outputs, slot copy where an episode ended, stores.
+template <typename ST>
+__device__ __forceinline__ void tile_step(const StepArgs& A, const DevParams& P, int64_t wave_base, int lane, float* wl, const TileIn<ST>& in) {
+  using V = typename Vec4<ST>::type;
+  const int64_t n = A.n, i = wave_base + lane;
+  const bool active = i < n;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  if (rows <= 0) return;   // wave-uniform
+  Env e;
+  unpack_chunks<ST>(in.c, e);
+  // actions: this lane's three float2 of the wave's 384 contiguous floats -> LDS -> own row (the region is reused for the observations)
+#pragma unroll
+  for (int q = 0; q < 3; ++q) *reinterpret_cast<float2*>(wl + q * 128 + lane * 2) = in.act[q];
+  wave_lds_fence();
+  float a[RDV_ACT_DIM];
+#pragma unroll
+  for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? wl[lane * RDV_ACT_DIM + j] : 0.0f;
+  wave_lds_fence();
+  StepResult r;
+  const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
+  const bool fin = stepped && r.done;
+#ifndef RDV_ABL_NOSTATS
+  stats_update(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, in.stat, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+#endif
+#ifdef RDV_ABL_NOSPARSE
+  store_step_outputs<true>(A, i, active, false, r, e);
+  const bool take = false;
+#else
+  store_step_outputs<true>(A, i, active, fin, r, e);
+  const bool take = fin && A.on_done == RDV_ON_DONE_RESET;
+#endif
+  if (take) A.prep_tag[i] = (e.episode + 1u) | kTagConsumed | kTagTake;   // refill_kernel continues this env from its slot (every slot is clean here)
+  else if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+  // observations: own row -> LDS (stride 17: conflict-free) -> contiguous stores (a finished env's row: its terminal observation,
+  // replaced by the first observation of the next episode when refill_kernel continues it)
+#pragma unroll
+  for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
+  wave_lds_fence();
+#ifndef RDV_ABL_NOOBSROWS
+  store_obs_rows(A.obs, wave_base, rows, lane, wl);
+#endif
+  wave_lds_fence();   // the region is rewritten by the next tile
+  // state write-back: 6 x 16-byte-per-lane stores
+#ifdef RDV_ABL_NOSTORE
+  if (stepped && !take && e.k < 0) store_env<ST>(reinterpret_cast<V*>(A.ws), n, i, e, false);
+#else
+  if (stepped && !take) store_env<ST>(reinterpret_cast<V*>(A.ws), n, i, e, false);
+#endif
+}
+
+// kTiles consecutive tiles per wave, software-pipelined: the inputs of tile j+1 are requested before tile j is computed, so a wave
+// always has ~9 KB of loads in flight behind ~1,300 instructions of arithmetic.  At >= 1 M envs the one-tile form (round 1, and
+// kTiles = 1 here) is bound by memory LATENCY, not by instructions or bandwidth: a wave's loads are outstanding only at its
+// beginning, ~35 KB in flight per CU on average where ~50 KB are needed to stream at 6 TB/s — removing 40 % of its instructions
+// (the in-lane reset) changed nothing (measured: 345 us per launch at 4 M envs, in-lane 330-350).
+template <typename ST, int kMinWaves, int kTiles>
 __global__ __launch_bounds__(kBlock, kMinWaves) void step_kernel_fused(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                                         uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   StepArgs A = A_rest;   // the seven hot arguments are preloaded into SGPRs (see step_kernel)
   A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
-  using V = typename Vec4<ST>::type;
   __shared__ __attribute__((aligned(16))) float lds[kBlock * RDV_OBS_DIM];   // 17,408 B: wave-private staging regions
   const DevParams& P = *Pp;   // scalar loads: see step_kernel
   const int lane = threadIdx.x & (kWave - 1);
   const int wave_in_block = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int64_t wave_base = i - lane;
-  const int64_t n = A.n;
-  const bool active = i < n;
-  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
   float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
-  V* ws = reinterpret_cast<V*>(A.ws);
-
-  Env e;
-  if (active) load_env<ST>(ws, n, i, e);
-  uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-  const uint64_t slot_pre = stats_preload(slot, lane);
-  float a[RDV_ACT_DIM];
-  load_actions(A.actions, wave_base, rows, lane, active, wl, a);
-
-  StepResult r;
-  const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
-  const bool fin = stepped && r.done;
-  stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-  store_step_outputs<true>(A, i, active, fin, r, e);
-  const bool take = fin && A.on_done == RDV_ON_DONE_RESET;
-  if (take) {   // auto-reset (SB3 DummyVecEnv semantics): the env continues from its prepared slot, the observation is the slot's
-    SlotRaw<ST> raw;
-    slot_fetch<ST>(hbm_slots<ST>(A), i, raw);      // 12 sparse 16-byte loads (the other waves of the SIMD cover their latency)
-    slot_unpack<ST>(P, raw, e, r.obs);
-    A.prep_tag[i] = e.episode | kTagConsumed;      // every slot is clean when this kernel starts (the host sees to it)
-  } else if (fin && A.on_done == RDV_ON_DONE_HALT) {
-    e.flags |= FLAG_HALTED;
+  const int64_t first = (((int64_t)blockIdx.x * (kBlock / kWave) + wave_in_block) * kTiles) * kWave;   // this wave's envs: [first, first + 64 kTiles)
+  TileIn<ST> cur;
+  tile_request<ST>(A, first, lane, cur);
+  if (kTiles == 1) {
+    tile_step<ST>(A, P, first, lane, wl, cur);
+    return;
   }
-  // observations: own row -> LDS (stride 17: conflict-free) -> contiguous stores
-#pragma unroll
-  for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
-  wave_lds_fence();
-  store_obs_rows(A.obs, wave_base, rows, lane, wl);
-  // state write-back: 6 x 16-byte-per-lane stores (7 where a slot was taken: wt)
-  if (stepped) store_env<ST>(ws, n, i, e, take);
+#pragma clang loop unroll(disable)
+  for (int j = 0; j < kTiles; ++j) {   // rolled: one copy of the tile code; the next tile's inputs travel while this one computes
+    int ln = lane;   // opaque copy: per-lane addresses are recomputed per tile instead of being kept in registers across the loop
+    asm volatile("" : "+v"(ln));
+    const int64_t base = first + (int64_t)j * kWave;
+    TileIn<ST> nxt = cur;
+    if (j + 1 < kTiles) tile_request<ST>(A, base + kWave, ln, nxt);
+    tile_step<ST>(A, P, base, ln, wl, cur);
+    cur = nxt;
+  }
 }
 
 // Refill of the marked slots.  One wave owns 1,024 consecutive envs: 16 tags per lane (4 x 16-byte loads), the marked ones are
@@ -466,7 +576,8 @@ __global__ __launch_bounds__(kBlock) void refill_kernel(const DevParams* __restr
     const int j = j0 + lane;
     if (j < total) {
       const int64_t i = base + list[j];
-      refill_whole<ST>(A, *Pp, i, A.prep_tag[i] & ~kTagConsumed);
+      const uint32_t tag = A.prep_tag[i];
+      refill_whole<ST>(A, *Pp, i, tag & kTagMask, (tag & kTagTake) != 0u);
     }
   }
 }
@@ -533,6 +644,12 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     const uint64_t slot_pre = stats_preload(slot, lane);
     float a[RDV_ACT_DIM];
     load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+#ifdef RDV_TOUCH
+    {   // the output pointers that are used only after the transition: fetched from the kernarg segment NOW, behind the state loads
+      const void *p1 = A.done, *p2 = A.terminal_obs, *p3 = A.episode_return, *p4 = A.episode_length, *p5 = A.done_reason;
+      asm volatile("" : : "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5));
+    }
+#endif
     RDV_STAMP(1);
     const bool marked = (tag & kTagConsumed) != 0u;   // the service waves refill this slot during this launch
     const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
@@ -542,12 +659,28 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     const bool take = to_reset && !marked;
     const bool late = to_reset && marked;
     const unsigned long long m_late = __ballot(late);
+    // (measured and dropped: requesting the slot ~150 instructions into the transition, where time-outs and bubble exits are already
+    //  decided — 8.46 us per launch against 8.22 at 65,536 envs: the 48 registers of the slot held across the transition cost more
+    //  than the ~0.4 us of load latency they hide.  Write-through `sc1` stores for state and rows, to spare the next launch the L2
+    //  write-back at the boundary: 10.8 us against 8.5.)
     SlotRaw<ST> raw;
-    if (take) slot_fetch<ST>(S, i, raw);      // 12 sparse 16-byte loads, in flight during the statistics and the output stores
+#ifndef RDV_ABL_NOTAKE
+    if (take) slot_fetch<ST>(S, i, raw);      // 12 sparse 16-byte loads of one record, in flight during the statistics and the output stores
+#endif
+#ifndef RDV_ABL_NOSTATS
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+#endif
+#ifdef RDV_ABL_NOSPARSE
+    store_step_outputs<true>(A, i, active, false, r, e);
+#else
     store_step_outputs<true>(A, i, active, fin, r, e);
+#endif
     RDV_STAMP(3);
+#ifndef RDV_ABL_NOTAKE
     if (take) slot_unpack<ST>(P, raw, e, r.obs);   // auto-reset (SB3 DummyVecEnv semantics): the first observation of the next episode
+#else
+    if (take) { e.k = 0; e.bubble = P.bubble_radius0; e.rc[1] = -10.0; e.rc[0] = 0.5; e.rc[2] = 0.1; e.vc[0] = e.vc[1] = e.vc[2] = 0.0; e.episode += 1u; }
+#endif
     else if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
     // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores
 #pragma unroll
@@ -561,7 +694,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     RDV_STAMP(6);
     // tags: this lane is the only writer of its env's tag in this launch
     if (take) A.prep_tag[i] = e.episode | kTagConsumed;
-    else if (marked && !late) A.prep_tag[i] = (tag & ~kTagConsumed) + 1u;          // refilled before the barrier: clean again
+    else if (marked && !late) A.prep_tag[i] = (tag & kTagMask) + 1u;          // refilled before the barrier: clean again
     if (m_late != 0ull) {   // wave-uniform, rare: an episode of a single step
       if (late) {
         slot_fetch<ST>(S, i, raw);            // written by the service waves of this workgroup before the barrier
@@ -593,7 +726,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       if (total > 0) {   // wave-uniform
 #pragma unroll
         for (int q = 0; q < kSplitWaves; ++q)
-          if (pend[q]) job_counter[role][q * kWave + lane] = tg[q] & ~kTagConsumed;
+          if (pend[q]) job_counter[role][q * kWave + lane] = tg[q] & kTagMask;
         wave_lds_fence();
 #pragma clang loop unroll(disable)
         for (int j0 = 0; j0 < total; j0 += kWave) {
@@ -616,6 +749,117 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
   RDV_STAMP(7);
   RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + wv)
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 1's split-role kernel ("next state beside the step"): waves 4-7 compute every env's next initial state and observation in
+// registers while waves 0-3 step; after the barrier a service lane whose env finished writes them.  No slots, no dependent loads.
+template <typename ST>
+__global__ __launch_bounds__(kSplitBlock) void step_kernel_split_r1(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+                                                       uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
+  // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
+  // at wave launch (-mllvm -amdgpu-kernarg-preload-count=16) instead of being fetched from the host-visible kernarg
+  // segment; the rest of the argument block is read later, off the critical path.
+  StepArgs A = A_rest;
+  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
+  using V = typename Vec4<ST>::type;
+  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // actions, then observation rows
+  __shared__ unsigned long long fin_mask[kSplitEnvs / kWave];                        // per step wave: lanes to reset
+  const DevParams& P = *Pp;   // scalar loads: see step_kernel
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = threadIdx.x >> 6;
+  const bool step_role = wv < kSplitEnvs / kWave;
+  const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);          // both roles: the env this lane is responsible for
+  const int64_t i = (int64_t)blockIdx.x * kSplitEnvs + slot_in_block;
+  const int64_t wave_base = i - lane;
+  const int64_t n = A.n;
+  const bool active = i < n;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  V* ws = reinterpret_cast<V*>(A.ws);
+  const bool resets = A.on_done == RDV_ON_DONE_RESET;
+  RDV_STAMP_DECL
+  RDV_STAMP(0);
+
+  if (step_role) {
+    // ------------------------------------------------------------------ step waves
+    float* wl = stage + wv * (kWave * RDV_OBS_DIM);
+    Env e;
+    StepResult r;
+    if (active) load_env<ST>(ws, n, i, e);
+    uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
+    const uint64_t slot_pre = stats_preload(slot, lane);
+    float a[RDV_ACT_DIM];
+    load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+    RDV_STAMP(1);
+    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
+    RDV_STAMP(2);
+    const bool fin = stepped && r.done;
+    const bool to_reset = fin && resets;
+    const unsigned long long m_reset = __ballot(to_reset);
+    if (lane == 0) fin_mask[wv] = m_reset;
+    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+    store_step_outputs<true>(A, i, active, fin, r, e);
+    RDV_STAMP(3);
+    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+    // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores.  If an env of this wave resets,
+    // the rows stay in LDS: the service wave swaps in the reset observation and stores the block after the barrier.
+#pragma unroll
+    for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
+    wave_lds_fence();
+#ifdef RDV_R1_PATCH
+    store_obs_rows(A.obs, wave_base, rows, lane, wl);
+#else
+    if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
+#endif
+    RDV_STAMP(4);
+    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
+    RDV_STAMP(5);
+    RDV_STAMP(6);
+    __syncthreads();
+  } else {
+    // ------------------------------------------------------------------ service waves
+    V packed[7];               // the next initial state, already in storage layout: nothing is left to compute after the barrier
+    float robs[RDV_OBS_DIM];
+    if (resets && active) {
+      Env ne;
+      const V c5 = ws[5 * n + i];
+      ne.episode = s2u(c5.w);
+      RDV_STAMP(1);
+      const double* row = nullptr;
+      if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
+      reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+      reset_aux<ST>(P, ne);
+      observation(P, ne, robs);
+      pack_env<ST>(ne, packed);
+      RDV_STAMP(2);
+    }
+    RDV_STAMP(3);
+    __syncthreads();
+    RDV_STAMP(4);
+    const unsigned long long m_reset = fin_mask[wv - kSplitEnvs / kWave];
+    if (m_reset != 0ull) {   // wave-uniform: some env of the step wave we serve finished its episode
+      float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
+      if (active && ((m_reset >> lane) & 1ull)) {
+        // auto-reset (SB3 DummyVecEnv semantics): the new state to HBM, the first observation of the next episode into the row
+        store_chunks<ST>(ws, n, i, packed, true);
+#ifdef RDV_R1_PATCH
+        float* row = A.obs + i * RDV_OBS_DIM;   // the step wave's block store has completed (its barrier's release): this lands last
+#pragma unroll
+        for (int j = 0; j < RDV_OBS_DIM; ++j) row[j] = robs[j];
+      }
+#else
+#pragma unroll
+        for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
+      }
+      wave_lds_fence();
+      store_obs_rows(A.obs, wave_base, rows, lane, wl);
+#endif
+    }
+    RDV_STAMP(6);
+  }
+  RDV_STAMP(7);
+  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + wv)
+}
+
 
 // reset() for all envs or where mask != 0; the env's prepared slot is refilled for the episode after the one that starts here
 template <typename ST>
@@ -717,8 +961,8 @@ static inline int64_t stats_bytes(int64_t n) { return align_up(n_waves(n) * kSta
 static inline int64_t params_bytes() { return align_up((int64_t)sizeof(DevParams), 256); }
 constexpr int kAcosEntries = 200001;   // acos(k/1e5), k = -100000..100000 (general.py:179 rounds every cosine to 5 decimals)
 static inline int64_t acos_bytes() { return align_up((int64_t)kAcosEntries * (int64_t)sizeof(double), 256); }
-// prepared next-episode states (rdv_slots.h): 7 chunk arrays like the state, 5 float4 observation arrays, one tag per env
-static inline int64_t prep_obs_bytes(int64_t n) { return align_up(kSlotObsVecs * n * 16, 256); }
+// prepared next-episode states (rdv_slots.h): one record per env (7 chunks + 5 float4 of observation), one tag per env
+static inline int64_t prep_bytes(int64_t n, int storage) { return align_up(n * (storage == RDV_STORAGE_F64 ? slot_record_bytes<double>() : slot_record_bytes<float>()), 256); }
 static inline int64_t prep_tag_bytes(int64_t n) { return align_up(n * 4, 256); }
 
 // Largest integer k in [-100000, 100000] for which acos(k/1e5) > theta (strict) or >= theta; -100001 if there is none.
@@ -817,12 +1061,12 @@ struct RdvEnvBatch {
   RdvRigidBody body; // rdv_set_rigid_body
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
   bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
-  void* prep;        // prepared next-episode states (rdv_slots.h): chunk arrays, observations, tags
-  float4* prep_obs;
+  void* prep;        // prepared next-episode states (rdv_slots.h): records, tags
   uint32_t* prep_tag;
   bool prepared_ok;  // every slot holds what the env's next reset returns (false: prepare_kernel runs before the next slot-using launch)
   bool tags_clean;   // no slot is marked "taken, refill pending" (step_kernel_split leaves marks for the next launch to refill)
-  int fused_min_waves;   // tuning: register budget of step_kernel_fused (3 or 4 waves per SIMD)
+  int fused_min_waves;   // tuning: register budget of step_kernel_fused (2 or 3 waves per SIMD)
+  int fused_tiles;       // tuning: tiles per wave of step_kernel_fused (0: by batch size)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
@@ -838,7 +1082,7 @@ static void apply_rigid_body(RdvEnvBatch* h);
 static void base_args(const RdvEnvBatch* h, StepArgs& A) {
   std::memset(&A, 0, sizeof A);
   A.ws = h->ws; A.stats = h->stats; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
-  A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.prep = h->prep; A.prep_obs = h->prep_obs; A.prep_tag = h->prep_tag;
+  A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.prep = h->prep; A.prep_tag = h->prep_tag;
 }
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
@@ -856,9 +1100,10 @@ static int ensure_prepared(RdvEnvBatch* h, hipStream_t s) {
   return RDV_OK;
 }
 // refill_kernel: every marked slot is refilled (the fused step kernel starts from clean slots and is followed by this)
-static int refill_marked(RdvEnvBatch* h, hipStream_t s) {
+static int refill_marked(RdvEnvBatch* h, hipStream_t s, float* obs) {
   StepArgs A;
   base_args(h, A);
+  A.obs = obs;
   const int64_t per_block = (int64_t)kRefillPerWave * (kBlock / kWave);
   const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
   if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(refill_kernel<float>, grid, dim3(kBlock), 0, s, h->dev_params, A);
@@ -919,7 +1164,7 @@ int rdv_params_validate(const RdvParams* p) {
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
   if (n_envs <= 0 || (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64)) return -1;
   return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes() + acos_bytes() +
-         chunk_bytes(n_envs, storage) + prep_obs_bytes(n_envs) + prep_tag_bytes(n_envs);
+         prep_bytes(n_envs, storage) + prep_tag_bytes(n_envs);
 }
 
 int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
@@ -1067,7 +1312,7 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   RolloutArgs A;
   A.ws = h->ws; A.stats = h->stats; A.obs = out->obs; A.actions = out->actions; A.reward = out->reward; A.done = out->done;
   A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.seed = h->seed;
-  A.prep = h->prep; A.prep_obs = h->prep_obs; A.prep_tag = h->prep_tag;
+  A.prep = h->prep; A.prep_tag = h->prep_tag;
   A.env_id_offset = h->env_id_offset; A.noise_seed = noise_seed; A.noise_counter0 = noise_counter0;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps; A.deterministic = deterministic ? 1 : 0;
   const dim3 grid((unsigned)((h->n + kRollEnvs - 1) / kRollEnvs)), block(kRollBlock);
@@ -1110,10 +1355,10 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->dev_params = reinterpret_cast<DevParams*>(reinterpret_cast<char*>(h->stats) + stats_bytes(n_envs));
   h->acos_table = reinterpret_cast<double*>(reinterpret_cast<char*>(h->dev_params) + params_bytes());
   h->prep = reinterpret_cast<char*>(h->acos_table) + acos_bytes();
-  h->prep_obs = reinterpret_cast<float4*>(static_cast<char*>(h->prep) + chunk_bytes(n_envs, storage));
-  h->prep_tag = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h->prep_obs) + prep_obs_bytes(n_envs));
-  h->prepared_ok = false; h->tags_clean = true; h->fused_min_waves = 3;
-  if (const char* v = std::getenv("RDV_FUSED_MIN_WAVES")) h->fused_min_waves = std::atoi(v) == 4 ? 4 : 3;   // tuning knob
+  h->prep_tag = reinterpret_cast<uint32_t*>(static_cast<char*>(h->prep) + prep_bytes(n_envs, storage));
+  h->prepared_ok = false; h->tags_clean = true; h->fused_min_waves = 2; h->fused_tiles = 0;
+  if (const char* v = std::getenv("RDV_FUSED_MIN_WAVES")) h->fused_min_waves = std::atoi(v) == 3 ? 3 : 2;   // tuning knobs
+  if (const char* v = std::getenv("RDV_FUSED_TILES")) { const int t = std::atoi(v); h->fused_tiles = (t == 1 || t == 2 || t == 4) ? t : 0; }
   h->dev.acos_table = h->acos_table;
   // every step of the set-up reports itself: which call failed, and why
   const char* what = "hipMemset of the workspace";
@@ -1259,7 +1504,7 @@ int rdv_debug_set_stamps(rdv_handle h, unsigned long long* stamps) {   // diagno
 #endif
 int rdv_set_kernel_variant(rdv_handle h, int variant) {
   RDV_CHECK_HANDLE(h);
-  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT && variant != RDV_VARIANT_INLANE)
+  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT && variant != RDV_VARIANT_INLANE && variant != RDV_VARIANT_SPLIT_R1)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_kernel_variant: bad variant %d", variant);
   h->variant = variant;
   return RDV_OK;
@@ -1312,6 +1557,14 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   const bool raw = h->raw_state && !h->general;   // (the RK45 kernels integrate the quaternion as given, like the reference)
   h->raw_state = false;
   const bool inlane = A.diag || h->general || raw || h->variant == RDV_VARIANT_INLANE;
+  if (!inlane && h->variant == RDV_VARIANT_SPLIT_R1) {
+    const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
+    if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL((step_kernel_split_r1<float>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+    else hipLaunchKernelGGL((step_kernel_split_r1<double>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
+    if (h->on_done == RDV_ON_DONE_RESET) h->prepared_ok = false;
+    RDV_HIP(hipGetLastError());
+    return RDV_OK;
+  }
 #define RDV_LAUNCH(KERNEL, GRID, BLOCK) hipLaunchKernelGGL((KERNEL), GRID, BLOCK, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A)
   if (!inlane) {
     if (int rc = ensure_prepared(h, s)) return rc;
@@ -1322,12 +1575,19 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
       if (h->storage == RDV_STORAGE_F32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
       if (resets) h->tags_clean = false;   // the slots taken in this launch are refilled by the next one
     } else {
-      if (resets && !h->tags_clean) { if (int rc = refill_marked(h, s)) return rc; }
-      const dim3 grid = grid_for(h->n), block(kBlock);
+      if (resets && !h->tags_clean) { if (int rc = refill_marked(h, s, A.obs)) return rc; }
+      // tiles of 64 envs per wave (software-pipelined): as many as leave >= ~6 waves per SIMD in the grid
+      const int64_t tiles = (h->n + kWave - 1) / kWave;
+      int per_wave = h->fused_tiles > 0 ? h->fused_tiles : (tiles >= 32768 ? 4 : (tiles >= 12288 ? 2 : 1));
+      if (h->storage == RDV_STORAGE_F64) per_wave = 1;   // (parity mode: a second set of 64-byte-per-lane inputs does not fit the registers)
+      const int64_t per_block = (int64_t)kBlock * per_wave;
+      const dim3 grid((unsigned)((h->n + per_block - 1) / per_block)), block(kBlock);
       const bool f32 = h->storage == RDV_STORAGE_F32;
-      if (h->fused_min_waves == 4) { if (f32) RDV_LAUNCH((step_kernel_fused<float, 4>), grid, block); else RDV_LAUNCH((step_kernel_fused<double, 4>), grid, block); }
-      else { if (f32) RDV_LAUNCH((step_kernel_fused<float, 3>), grid, block); else RDV_LAUNCH((step_kernel_fused<double, 3>), grid, block); }
-      if (resets) { if (int rc = refill_marked(h, s)) return rc; }
+      if (!f32) RDV_LAUNCH((step_kernel_fused<double, 3, 1>), grid, block);
+      else if (per_wave == 1) RDV_LAUNCH((step_kernel_fused<float, 3, 1>), grid, block);
+      else if (h->fused_min_waves == 3) { if (per_wave == 4) RDV_LAUNCH((step_kernel_fused<float, 3, 4>), grid, block); else RDV_LAUNCH((step_kernel_fused<float, 3, 2>), grid, block); }
+      else { if (per_wave == 4) RDV_LAUNCH((step_kernel_fused<float, 2, 4>), grid, block); else RDV_LAUNCH((step_kernel_fused<float, 2, 2>), grid, block); }
+      if (resets) { if (int rc = refill_marked(h, s, A.obs)) return rc; }
     }
   } else {
     const dim3 grid = grid_for(h->n), block(kBlock);
@@ -1368,7 +1628,7 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   StepManyArgs A;
   A.ws = h->ws; A.stats = h->stats; A.actions = actions; A.obs = out->obs; A.reward = out->reward; A.done = out->done;
   A.done_reason = out->done_reason; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
-  A.prep = h->prep; A.prep_obs = h->prep_obs; A.prep_tag = h->prep_tag;
+  A.prep = h->prep; A.prep_tag = h->prep_tag;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps;
   const dim3 grid((unsigned)((h->n + kManyEnvs - 1) / kManyEnvs)), block(kManyBlock);
   if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(step_many_kernel<float>, grid, block, many_lds_bytes<float>(), s, h->dev_params, A);

@@ -57,7 +57,6 @@ struct RolloutArgs {
   float* last_obs;          // [N][17]  observation after the last step (SB3 _last_obs)
   const double* tape;       // nullable [depth][N][20]
   void* prep;               // prepared next-episode states in HBM (rdv_slots.h)
-  float4* prep_obs;
   uint32_t* prep_tag;
   int64_t n;
   uint64_t seed;            // reset RNG (as rdv_step)
@@ -82,11 +81,10 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   uint64_t* stat_lds = reinterpret_cast<uint64_t*>(act_cur + kRollEnvs * RDV_ACT_DIM);   // [4][16]: the rollout's statistics per env wave
   uint32_t* job_kind = reinterpret_cast<uint32_t*>(stat_lds + kRollEnvWaves * kStatWords);   // [256]
   uint32_t* job_counter = job_kind + kRollEnvs;                                              // [256]
-  SlotStore<ST> L;                                                                           // the workgroup's slots
-  L.chunks = reinterpret_cast<V*>(job_counter + kRollEnvs);                                  // [7][256]
-  L.obs = reinterpret_cast<float4*>(L.chunks + kChunks * kRollEnvs);                         // [5][256]
-  L.n = kRollEnvs;
-  uint16_t* lists = reinterpret_cast<uint16_t*>(L.obs + kSlotObsVecs * kRollEnvs);           // [4][256]
+  V* slot_chunks = reinterpret_cast<V*>(job_counter + kRollEnvs);                            // [7][256]
+  float4* slot_obs = reinterpret_cast<float4*>(slot_chunks + kChunks * kRollEnvs);           // [5][256]
+  const SlotStore<ST> L = lds_slot_store<ST>(slot_chunks, slot_obs, kRollEnvs);              // the workgroup's slots
+  uint16_t* lists = reinterpret_cast<uint16_t*>(slot_obs + kSlotObsVecs * kRollEnvs);        // [4][256]
   const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform
   const DevParams& P = *Pp;   // scalar loads (see step_kernel)
   const int lane = threadIdx.x & (kWave - 1);
@@ -110,8 +108,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   e.episode = 0u;
   bool wt_dirty = false;
   bool slot_dirty = false;   // this env's slot in LDS differs from the one in HBM
-  SlotStore<ST> H;           // the slots in HBM
-  H.chunks = reinterpret_cast<V*>(A.prep); H.obs = A.prep_obs; H.n = n;
+  const SlotStore<ST> H = hbm_slot_store<ST>(A.prep);   // the slots in HBM
   uint64_t* my_stats = stat_lds + (wv & (kRollEnvWaves - 1)) * kStatWords;
   if (env_role) {
     if (lane < kStatWords) my_stats[lane] = 0ull;

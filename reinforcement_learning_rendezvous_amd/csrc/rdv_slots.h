@@ -3,7 +3,8 @@
 //
 // A reset depends only on (seed, global env id, episode index) — or on a row of the reset tape — so it can be computed any time
 // before it is needed.  Round 1 computed it for every env in every launch (service waves) or in-lane where an episode ended
-// (divergent: ~96 % of the waves ran the ~900-instruction reset for ~5 % of their lanes).  Now every env owns a slot in HBM:
+// (divergent: ~96 % of the waves ran the ~900-instruction reset for ~5 % of their lanes).  Now every env owns a slot in HBM, one
+// record per env:
 //     7 state chunks in storage layout (the state reset() produces, bookkeeping included: t = 0, bubble_radius0, totals 0,
 //     collided / success of the initial state, episode index + 1)  +  its observation (17 floats in 5 float4)  +  a tag.
 // A lane whose episode ends COPIES its slot (12 sparse 16-byte loads, issued while the episode statistics are reduced) instead of
@@ -16,13 +17,16 @@
 // tag[i] = (episode index the slot's state carries, i.e. the index of the episode it starts, + 1 ... see below) | kTagConsumed:
 //   clean  : tag == e.episode + 1   — the slot holds reset(seed, id, counter = e.episode), whose own episode field is e.episode + 1
 //   marked : tag & kTagConsumed     — the slot was copied into the env by a launch that leaves the refill to the next launch;
-//            (tag & ~kTagConsumed) == e.episode is the counter to refill it with.
+//            (tag & kTagMask) == e.episode is the counter to refill it with.  With kTagTake as well (step_kernel_fused hands the
+//            copy itself to refill_kernel, launched right behind it): the env has ended its episode and still waits for the slot.
 // Results are bit-identical to the in-lane reset (same expressions on the same inputs); every equality test of round 1 holds.
 #pragma once
 
 namespace rdv {
 
 constexpr uint32_t kTagConsumed = 0x80000000u;
+constexpr uint32_t kTagTake = 0x40000000u;       // (with kTagConsumed, step_kernel_fused -> refill_kernel) the env has yet to take the slot
+constexpr uint32_t kTagMask = ~(kTagConsumed | kTagTake);
 constexpr int kSlotObsVecs = 5;            // 17 observation floats in 5 float4 (3 pad)
 enum : uint32_t { JOB_NONE = 0, JOB_REFILL = 1, JOB_FALLBACK = 2 };
 // flags word of a slot that was refilled by part and whose state lies close enough to the target for collided / success (:261-262)
@@ -30,24 +34,47 @@ enum : uint32_t { JOB_NONE = 0, JOB_REFILL = 1, JOB_FALLBACK = 2 };
 // nominal start 10 m out; keeps the whole-state arithmetic out of the refilling waves)
 constexpr uint32_t kFlagsPending = 0xFFFFFFFFu;
 
-// Slot storage, struct-of-arrays like the state: chunk c of entry i at chunks[c * n + i], observation vector v at obs[v * n + i].
-// HBM: n = batch size, i = env.  Persistent kernels keep their workgroup's slots in LDS: n = envs per workgroup, i = lane slot.
+// Slot storage: chunk c of entry i at chunks[c * cs + i * es], observation vector v at obs[v * ocs + i * oes].
+//   HBM (hbm_slot_store): ONE RECORD PER ENV — 7 chunks then 5 observation vectors, 192 B (float) / 320 B (double, padded) — because
+//   slots are touched sparsely (the ~5 % of envs whose episode ended): a record is 2-3 cache lines and one page, where the
+//   struct-of-arrays form of the first version cost 12 lines in 12 arrays per env (measured at 4 M envs: the step kernel 414 us
+//   against 332 us for the in-lane reset it replaced, the refill 103 us, both bound by those 16-byte accesses).
+//   LDS (persistent kernels keep their workgroup's slots there): struct-of-arrays, conflict-free 16-byte accesses.
 template <typename ST>
 struct SlotStore {
   typename Vec4<ST>::type* chunks;
   float4* obs;
-  int64_t n;
+  int64_t cs, es, ocs, oes;
+  __device__ __forceinline__ typename Vec4<ST>::type* chunk(int c, int64_t i) const { return chunks + (c * cs + i * es); }
+  __device__ __forceinline__ float4* ovec(int v, int64_t i) const { return obs + (v * ocs + i * oes); }
 };
+template <typename ST> constexpr int slot_record_bytes() { return sizeof(ST) == 4 ? 192 : 320; }
+template <typename ST>
+__device__ __forceinline__ SlotStore<ST> hbm_slot_store(void* prep) {
+  using V = typename Vec4<ST>::type;
+  SlotStore<ST> S;
+  S.chunks = reinterpret_cast<V*>(prep);
+  S.obs = reinterpret_cast<float4*>(S.chunks + kChunks);
+  S.cs = 1; S.es = slot_record_bytes<ST>() / (int)sizeof(V);
+  S.ocs = 1; S.oes = slot_record_bytes<ST>() / 16;
+  return S;
+}
+template <typename ST>
+__device__ __forceinline__ SlotStore<ST> lds_slot_store(typename Vec4<ST>::type* chunks, float4* obs, int entries) {
+  SlotStore<ST> S;
+  S.chunks = chunks; S.obs = obs; S.cs = entries; S.es = 1; S.ocs = entries; S.oes = 1;
+  return S;
+}
 
 template <typename ST>
 __device__ __forceinline__ void slot_store_full(const SlotStore<ST>& S, int64_t i, const Env& ne, const float* o) {
   typename Vec4<ST>::type c[kChunks];
   pack_env<ST>(ne, c);
 #pragma unroll
-  for (int k = 0; k < kChunks; ++k) S.chunks[k * S.n + i] = c[k];
+  for (int k = 0; k < kChunks; ++k) *S.chunk(k, i) = c[k];
 #pragma unroll
-  for (int v = 0; v < 4; ++v) S.obs[v * S.n + i] = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
-  S.obs[4 * S.n + i] = make_float4(o[16], 0.0f, 0.0f, 0.0f);
+  for (int v = 0; v < 4; ++v) *S.ovec(v, i) = make_float4(o[4 * v], o[4 * v + 1], o[4 * v + 2], o[4 * v + 3]);
+  *S.ovec(4, i) = make_float4(o[16], 0.0f, 0.0f, 0.0f);
 }
 
 // the raw 12 vectors of a slot (issued early, unpacked after other work: the loads are in flight meanwhile)
@@ -59,9 +86,9 @@ struct SlotRaw {
 template <typename ST>
 __device__ __forceinline__ void slot_fetch(const SlotStore<ST>& S, int64_t i, SlotRaw<ST>& raw) {
 #pragma unroll
-  for (int k = 0; k < kChunks; ++k) raw.c[k] = S.chunks[k * S.n + i];
+  for (int k = 0; k < kChunks; ++k) raw.c[k] = *S.chunk(k, i);
 #pragma unroll
-  for (int v = 0; v < kSlotObsVecs; ++v) raw.o[v] = S.obs[v * S.n + i];
+  for (int v = 0; v < kSlotObsVecs; ++v) raw.o[v] = *S.ovec(v, i);
 }
 template <typename ST>
 __device__ __forceinline__ void slot_unpack(const DevParams& P, const SlotRaw<ST>& raw, Env& e, float* o) {
@@ -83,9 +110,9 @@ __device__ __forceinline__ void slot_unpack(const DevParams& P, const SlotRaw<ST
 template <typename ST>
 __device__ __forceinline__ void slot_copy(const SlotStore<ST>& D, int64_t di, const SlotStore<ST>& S, int64_t si) {
 #pragma unroll
-  for (int k = 0; k < kChunks; ++k) D.chunks[k * D.n + di] = S.chunks[k * S.n + si];
+  for (int k = 0; k < kChunks; ++k) *D.chunk(k, di) = *S.chunk(k, si);
 #pragma unroll
-  for (int v = 0; v < kSlotObsVecs; ++v) D.obs[v * D.n + di] = S.obs[v * S.n + si];
+  for (int v = 0; v < kSlotObsVecs; ++v) *D.ovec(v, di) = *S.ovec(v, si);
 }
 
 __device__ __forceinline__ const double* tape_row_of(const double* tape, int32_t depth, int64_t n, int64_t i, uint32_t counter) {
@@ -112,21 +139,21 @@ __device__ __forceinline__ void slot_refill_part(const DevParams& P, const SlotS
   Env ne;
   ne.episode = counter;
   reset_fields<ST, kPart>(P, ne, seed, env_id, tape_row);
-  ST* c1 = reinterpret_cast<ST*>(&S.chunks[1 * S.n + i]);
-  ST* c2 = reinterpret_cast<ST*>(&S.chunks[2 * S.n + i]);
-  float* o0 = reinterpret_cast<float*>(&S.obs[0 * S.n + i]);
-  float* o1 = reinterpret_cast<float*>(&S.obs[1 * S.n + i]);
-  float* o2 = reinterpret_cast<float*>(&S.obs[2 * S.n + i]);
-  float* o3 = reinterpret_cast<float*>(&S.obs[3 * S.n + i]);
+  ST* c1 = reinterpret_cast<ST*>(S.chunk(1, i));
+  ST* c2 = reinterpret_cast<ST*>(S.chunk(2, i));
+  float* o0 = reinterpret_cast<float*>(S.ovec(0, i));
+  float* o1 = reinterpret_cast<float*>(S.ovec(1, i));
+  float* o2 = reinterpret_cast<float*>(S.ovec(2, i));
+  float* o3 = reinterpret_cast<float*>(S.ovec(3, i));
   if (kPart == RESET_RC_VC) {
     const uint32_t flags = reset_flags_needed(P, ne) ? kFlagsPending : 0u;
     typename Vec4<ST>::type v0, v5;
     v0.x = (ST)ne.rc[0]; v0.y = (ST)ne.rc[1]; v0.z = (ST)ne.rc[2]; v0.w = (ST)ne.vc[0];
-    S.chunks[0 * S.n + i] = v0;
+    *S.chunk(0, i) = v0;
     c1[0] = (ST)ne.vc[1]; c1[1] = (ST)ne.vc[2];
     c2[1] = (ST)canon(P.bubble_radius0, t); c2[2] = ST(0); c2[3] = ST(0);                      // reset_aux (:263-265)
     v5.x = ST(0); v5.y = u2s(0u, t); v5.z = u2s(flags, t); v5.w = u2s(counter + 1u, t);        // ep_return, k (:266), flags, episode
-    S.chunks[5 * S.n + i] = v5;
+    *S.chunk(5, i) = v5;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float a = normalized(ne.rc[j], P.obs_lo_r, P.obs_span_r, P.obs_inv_span_r);
@@ -137,7 +164,7 @@ __device__ __forceinline__ void slot_refill_part(const DevParams& P, const SlotS
   } else if (kPart == RESET_QC_WC) {
     typename Vec4<ST>::type v3;
     v3.x = (ST)ne.qc[0]; v3.y = (ST)ne.qc[1]; v3.z = (ST)ne.qc[2]; v3.w = (ST)ne.qc[3];
-    S.chunks[3 * S.n + i] = v3;
+    *S.chunk(3, i) = v3;
     c1[2] = (ST)ne.wc[0]; c1[3] = (ST)ne.wc[1]; c2[0] = (ST)ne.wc[2];
     o1[2] = (float)ne.qc[0]; o1[3] = (float)ne.qc[1]; o2[0] = (float)ne.qc[2]; o2[1] = (float)ne.qc[3];
     o2[2] = normalized(ne.wc[0], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
@@ -146,13 +173,13 @@ __device__ __forceinline__ void slot_refill_part(const DevParams& P, const SlotS
   } else if (kPart == RESET_QT) {
     typename Vec4<ST>::type v4;
     v4.x = (ST)ne.qt[0]; v4.y = (ST)ne.qt[1]; v4.z = (ST)ne.qt[2]; v4.w = (ST)ne.qt[3];
-    S.chunks[4 * S.n + i] = v4;
+    *S.chunk(4, i) = v4;
     o3[1] = (float)ne.qt[0]; o3[2] = (float)ne.qt[1]; o3[3] = (float)ne.qt[2];
-    S.obs[4 * S.n + i] = make_float4((float)ne.qt[3], 0.0f, 0.0f, 0.0f);
+    *S.ovec(4, i) = make_float4((float)ne.qt[3], 0.0f, 0.0f, 0.0f);
   } else {
     typename Vec4<ST>::type v6;
     v6.x = (ST)ne.wt[0]; v6.y = (ST)ne.wt[1]; v6.z = (ST)ne.wt[2]; v6.w = ST(0);
-    S.chunks[6 * S.n + i] = v6;
+    *S.chunk(6, i) = v6;
   }
 }
 template <typename ST>

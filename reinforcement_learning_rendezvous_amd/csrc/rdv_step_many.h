@@ -36,7 +36,6 @@ struct StepManyArgs {
   uint8_t* done_reason;     // nullable [K][N]
   const double* tape;       // nullable [depth][N][20]
   void* prep;               // prepared next-episode states in HBM (rdv_slots.h)
-  float4* prep_obs;
   uint32_t* prep_tag;
   int64_t n;
   uint64_t seed;
@@ -55,11 +54,10 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
   uint32_t* job_kind = reinterpret_cast<uint32_t*>(act_rows + kManyEnvs * RDV_ACT_DIM);   // [256]
   uint32_t* job_counter = job_kind + kManyEnvs;                                    // [256]
   uint64_t* stat_lds = reinterpret_cast<uint64_t*>(job_counter + kManyEnvs);       // [4][16]
-  SlotStore<ST> L;                                                                 // the workgroup's slots
-  L.chunks = reinterpret_cast<V*>(stat_lds + kManyEnvWaves * kStatWords);          // [7][256]
-  L.obs = reinterpret_cast<float4*>(L.chunks + kChunks * kManyEnvs);               // [5][256]
-  L.n = kManyEnvs;
-  uint16_t* lists = reinterpret_cast<uint16_t*>(L.obs + kSlotObsVecs * kManyEnvs); // [4][256]
+  V* slot_chunks = reinterpret_cast<V*>(stat_lds + kManyEnvWaves * kStatWords);   // [7][256]
+  float4* slot_obs = reinterpret_cast<float4*>(slot_chunks + kChunks * kManyEnvs); // [5][256]
+  const SlotStore<ST> L = lds_slot_store<ST>(slot_chunks, slot_obs, kManyEnvs);    // the workgroup's slots
+  uint16_t* lists = reinterpret_cast<uint16_t*>(slot_obs + kSlotObsVecs * kManyEnvs); // [4][256]
   const DevParams& P = *Pp;   // scalar loads (see step_kernel)
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
@@ -82,8 +80,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     float* my_act = act_rows + (slot - lane) * RDV_ACT_DIM;
     uint64_t* my_stats = stat_lds + wv * kStatWords;
     if (lane < kStatWords) my_stats[lane] = 0ull;
-    SlotStore<ST> H;   // the slots in HBM
-    H.chunks = reinterpret_cast<V*>(A.prep); H.obs = A.prep_obs; H.n = n;
+    const SlotStore<ST> H = hbm_slot_store<ST>(A.prep);   // the slots in HBM
     Env e;
     e.episode = 0u;
     bool slot_dirty = false;   // this env's slot in LDS differs from the one in HBM

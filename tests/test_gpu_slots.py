@@ -67,6 +67,10 @@ def test_all_kernel_layouts_give_the_in_lane_results(case):
     ref = _batch(n, params=p, storage=storage, seed=21, variant="inlane")
     envs = {v: _batch(n, params=p, storage=storage, seed=21, variant=v) for v in ("fused", "split")}
     envs["mixed"] = _batch(n, params=p, storage=storage, seed=21, variant="split")
+    for tiles in ("2", "4"):          # the software-pipelined forms of the fused kernel (chosen by batch size in production)
+        os.environ["RDV_FUSED_TILES"] = tiles
+        envs["fused, %s tiles per wave" % tiles] = _batch(n, params=p, storage=storage, seed=21, variant="fused")
+    os.environ.pop("RDV_FUSED_TILES")
     o0 = ref.reset().clone()
     for v, e in envs.items():
         _same(o0, e.reset(), f"{v}: reset obs")

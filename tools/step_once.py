@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Diagnostic workload for rocprofv3 --pmc: a few launches of rdv_step at N envs with a given kernel variant.
+
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY ... --kernel-trace --output-format csv -d out -- python3 tools/step_once.py 4194304 fused 8"""
+import os
+import sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+variant = sys.argv[2] if len(sys.argv) > 2 else "auto"
+launches = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+storage = sys.argv[4] if len(sys.argv) > 4 else "f32"
+env = RendezvousBatch(n, device="cuda:0", storage=storage, seed=0, variant=variant)
+gen = torch.Generator(device="cuda:0").manual_seed(1)
+acts = [(torch.rand((n, 6), device="cuda:0", generator=gen) * 2 - 1).contiguous() for _ in range(4)]
+env.reset()
+for t in range(24 + launches):       # the first 24 bring the batch into the steady state of the reset mix
+    env.step(acts[t % 4])
+torch.cuda.synchronize()
+print("done", n, variant, env.get_stats()["episodes"], flush=True)
