@@ -60,16 +60,12 @@ typedef enum RdvOnDone {
                               reports done again and counts as a finished episode in the statistics */
 } RdvOnDone;
 
-/* Which step kernel rdv_step launches.  All give the same results (same arithmetic); they differ in how the work of a
- * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 98304) and FUSED above.
- * FUSED and SPLIT take an env's next initial state from its prepared slot (a copy) and refill the slot once per episode. */
+/* Which step kernel rdv_step launches.  Both give the same results (same arithmetic); they differ in how the work of a
+ * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 98304) and FUSED above. */
 typedef enum RdvKernelVariant {
   RDV_VARIANT_AUTO = 0,
-  RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs; one wave per 512 envs refills the slots that were used */
-  RDV_VARIANT_SPLIT = 2,  /* step waves + service waves that refill the slots of the previous launch beside them, by part */
-  RDV_VARIANT_SPLIT_R1 = 4, /* (experimental) round 1's split kernel */
-  RDV_VARIANT_INLANE = 3  /* round 1's layout: resets computed divergently in the lane whose episode ended (the kernel of the
-                             evaluator-diagnostics / rigid-body / first-step-after-set_state configurations; a reference for the others) */
+  RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs, resets run divergently in-lane */
+  RDV_VARIANT_SPLIT = 2   /* step waves + service waves that precompute every env's next initial state beside them */
 } RdvKernelVariant;
 
 /*
@@ -157,7 +153,7 @@ int rdv_params_default(RdvParams* out_host);
 int rdv_params_validate(const RdvParams* params_host);
 
 /* Bytes of device memory one batch needs (persistent SoA state + stats + parameter block + acos table + the prepared
- * next-episode state of every env: 7 chunks, its observation and a tag). Host-only. */
+ * next-episode state of every env that the persistent kernels rdv_step_many / rdv_rollout keep: one record and a tag). Host-only. */
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage);
 
 /*

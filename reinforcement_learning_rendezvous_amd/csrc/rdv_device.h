@@ -678,11 +678,7 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   for (int i = 0; i < 4; ++i) e.qc[i] = canon(e.qc[i], tag);
   double Rc[9], inv_dist;
   derive_chaser(P, e, d, Rc, inv_dist);
-#ifdef RDV_ABL_NOACOS
-  const double att = 0.1 + 1e-9 * d.k_att;
-#else
   const double att = attitude_error_of(P, d.k_att);
-#endif
   // target side (:184)
   if (kGeneral) {
     integrate_attitude_rk45(e.qt, e.wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);

@@ -125,7 +125,7 @@ struct StepArgs {
   uint64_t env_id_offset;
   int32_t tape_depth;
   int32_t on_done;
-  void* prep;               // prepared next-episode states (csrc/rdv_slots.h): one record per env
+  void* prep;               // prepared next-episode states of the persistent kernels (csrc/rdv_slots.h): one record per env
   uint32_t* prep_tag;       // [N]
 #ifdef RDV_STAMPS
   unsigned long long* stamps;
@@ -307,9 +307,8 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// In-lane variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).  Round 1's
-// fused kernel; now the kernel of the cold configurations only — evaluator diagnostics (kDiag), general rigid bodies (kGeneral),
-// the first step after rdv_set_state (kRaw).  It does not use the prepared-state slots (the host re-prepares them afterwards).
+// Fused variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).
+// The right shape when the chip is full (several waves per SIMD): no work is done twice, and the reset adds no memory traffic.
 // kGeneral: general rigid bodies (rdv_set_rigid_body) — the attitude of both bodies is integrated with the reference's RK45
 // scheme instead of the closed form, and the target's rate is part of the state that is written back.
 // kRaw: the first step after rdv_set_state (quaternions that need not be normalised, see integrate_attitude).
@@ -376,215 +375,19 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
 #include "rdv_slots.h"
 namespace rdv {
 
-// ---------------------------------------------------------------------------------------------------------------
-// Fused variant (the chip is full: several waves per SIMD, N > ~98k envs): every wave does the whole transition for its 64 envs.
-// A lane whose episode ends only MARKS its prepared slot (rdv_slots.h): no reset arithmetic, no barrier, no second role and no
-// dependent memory access in the step path, which is then a pure stream — what it costs otherwise: with the slot copied in the
-// step wave (12 sparse loads, waited for in ~96 % of the waves) the kernel took as long as with the in-lane reset, 59 % of its
-// wave-cycles parked on s_waitcnt (profiles/r02_sq_counters_4M.csv).  refill_kernel, launched right behind on the same stream, finds
-// the marked slots by their tags (one wave compacts the marks of 1,024 envs: ~51 per step with random actions), copies each into its
-// env (state, first observation of the new episode) and runs the reset for the following episode DENSELY, one pass at ~80 % lane use:
-// the reset costs ~5 % of a step's instructions instead of the ~40 % of the divergent in-lane form.
-// kMinWaves: waves per SIMD the register allocation is held to (256-thread workgroups: 3 -> 168 VGPRs, 4 -> 128).
+// The whole reset of episode `counter` into env i's slot in HBM (one lane per env): prepare_kernel, reset_kernel.
 template <typename ST>
-__device__ __forceinline__ SlotStore<ST> hbm_slots(const StepArgs& A) { return hbm_slot_store<ST>(A.prep); }
-
-// The whole reset of episode `counter` into env i's slot (one lane per env): refill_kernel, prepare_kernel, reset_kernel.
-// take: the env first continues from what the slot holds (auto-reset, SB3 DummyVecEnv semantics: its state, and the first
-// observation of the new episode as the step's returned observation).
-template <typename ST>
-__device__ __forceinline__ void refill_whole(const StepArgs& A, const DevParams& P, int64_t i, uint32_t counter, bool take = false) {
-  if (take) {
-    SlotRaw<ST> raw;
-    slot_fetch<ST>(hbm_slots<ST>(A), i, raw);
-    Env cont;
-    float co[RDV_OBS_DIM];
-    slot_unpack<ST>(P, raw, cont, co);
-    store_env<ST>(reinterpret_cast<typename Vec4<ST>::type*>(A.ws), A.n, i, cont, true);
-    float* row = A.obs + i * RDV_OBS_DIM;
-#pragma unroll
-    for (int j = 0; j < RDV_OBS_DIM; ++j) row[j] = co[j];
-  }
+__device__ __forceinline__ void refill_whole(const StepArgs& A, const DevParams& P, int64_t i, uint32_t counter) {
   Env ne;
   float o[RDV_OBS_DIM];
   reset_whole<ST>(P, ne, o, A.seed, A.env_id_offset + (uint64_t)i, counter, tape_row_of(A.tape, A.tape_depth, A.n, i, counter));
-  slot_store_full<ST>(hbm_slots<ST>(A), i, ne, o);
+  slot_store_full<ST>(hbm_slot_store<ST>(A.prep), i, ne, o);
   A.prep_tag[i] = counter + 1u;
 }
 
-// The inputs of one tile of 64 envs, as requested from memory (nothing waits for them here): the seven state chunks, the wave's
-// action rows [64][6] (3 x float2 per lane, transposed through LDS when they are used) and the wave's statistics slot.
-template <typename ST>
-struct TileIn {
-  typename Vec4<ST>::type c[kChunks];
-  float2 act[3];
-  uint64_t stat;
-};
-template <typename ST>
-__device__ __forceinline__ void tile_request(const StepArgs& A, int64_t wave_base, int lane, TileIn<ST>& in) {
-  using V = typename Vec4<ST>::type;
-  const int64_t n = A.n, i = wave_base + lane;
-  const V* ws = reinterpret_cast<const V*>(A.ws);
-  if (i < n) {
-#pragma unroll
-    for (int k = 0; k < kChunks; ++k) in.c[k] = ws[k * n + i];
-  }
-  const int64_t valid = ((n - wave_base) < kWave ? (n - wave_base) : kWave) * RDV_ACT_DIM;
-  const float* src = A.actions + wave_base * RDV_ACT_DIM;
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int idx = q * 128 + lane * 2;
-    in.act[q] = make_float2(0.0f, 0.0f);
-    if (idx + 1 < valid) in.act[q] = *reinterpret_cast<const float2*>(src + idx);
-    else if (idx < valid) in.act[q].x = src[idx];
-  }
-  in.stat = valid > 0 ? stats_preload(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, lane) : 0ull;
-}
-template <typename ST>
-__device__ __forceinline__ void unpack_chunks(const typename Vec4<ST>::type* c, Env& e) {
-  e.rc[0] = c[0].x; e.rc[1] = c[0].y; e.rc[2] = c[0].z; e.vc[0] = c[0].w;
-  e.vc[1] = c[1].x; e.vc[2] = c[1].y; e.wc[0] = c[1].z; e.wc[1] = c[1].w;
-  e.wc[2] = c[2].x; e.bubble = c[2].y; e.sum_dv = c[2].z; e.sum_dw = c[2].w;
-  e.qc[0] = c[3].x; e.qc[1] = c[3].y; e.qc[2] = c[3].z; e.qc[3] = c[3].w;
-  e.qt[0] = c[4].x; e.qt[1] = c[4].y; e.qt[2] = c[4].z; e.qt[3] = c[4].w;
-  e.ep_ret = c[5].x; e.k = (int32_t)s2u(c[5].y); e.flags = s2u(c[5].z); e.episode = s2u(c[5].w);
-  e.wt[0] = c[6].x; e.wt[1] = c[6].y; e.wt[2] = c[6].z;
-}
-
-// One tile: transition, statistics, outputs, slot copy where an episode ended, stores.
-template <typename ST>
-__device__ __forceinline__ void tile_step(const StepArgs& A, const DevParams& P, int64_t wave_base, int lane, float* wl, const TileIn<ST>& in) {
-  using V = typename Vec4<ST>::type;
-  const int64_t n = A.n, i = wave_base + lane;
-  const bool active = i < n;
-  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
-  if (rows <= 0) return;   // wave-uniform
-  Env e;
-  unpack_chunks<ST>(in.c, e);
-  // actions: this lane's three float2 of the wave's 384 contiguous floats -> LDS -> own row (the region is reused for the observations)
-#pragma unroll
-  for (int q = 0; q < 3; ++q) *reinterpret_cast<float2*>(wl + q * 128 + lane * 2) = in.act[q];
-  wave_lds_fence();
-  float a[RDV_ACT_DIM];
-#pragma unroll
-  for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? wl[lane * RDV_ACT_DIM + j] : 0.0f;
-  wave_lds_fence();
-  StepResult r;
-  const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
-  const bool fin = stepped && r.done;
-#ifndef RDV_ABL_NOSTATS
-  stats_update(A.stats + (uint64_t)(wave_base / kWave) * kStatWords, in.stat, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-#endif
-#ifdef RDV_ABL_NOSPARSE
-  store_step_outputs<true>(A, i, active, false, r, e);
-  const bool take = false;
-#else
-  store_step_outputs<true>(A, i, active, fin, r, e);
-  const bool take = fin && A.on_done == RDV_ON_DONE_RESET;
-#endif
-  if (take) A.prep_tag[i] = (e.episode + 1u) | kTagConsumed | kTagTake;   // refill_kernel continues this env from its slot (every slot is clean here)
-  else if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-  // observations: own row -> LDS (stride 17: conflict-free) -> contiguous stores (a finished env's row: its terminal observation,
-  // replaced by the first observation of the next episode when refill_kernel continues it)
-#pragma unroll
-  for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
-  wave_lds_fence();
-#ifndef RDV_ABL_NOOBSROWS
-  store_obs_rows(A.obs, wave_base, rows, lane, wl);
-#endif
-  wave_lds_fence();   // the region is rewritten by the next tile
-  // state write-back: 6 x 16-byte-per-lane stores
-#ifdef RDV_ABL_NOSTORE
-  if (stepped && !take && e.k < 0) store_env<ST>(reinterpret_cast<V*>(A.ws), n, i, e, false);
-#else
-  if (stepped && !take) store_env<ST>(reinterpret_cast<V*>(A.ws), n, i, e, false);
-#endif
-}
-
-// kTiles consecutive tiles per wave, software-pipelined: the inputs of tile j+1 are requested before tile j is computed, so a wave
-// always has ~9 KB of loads in flight behind ~1,300 instructions of arithmetic.  At >= 1 M envs the one-tile form (round 1, and
-// kTiles = 1 here) is bound by memory LATENCY, not by instructions or bandwidth: a wave's loads are outstanding only at its
-// beginning, ~35 KB in flight per CU on average where ~50 KB are needed to stream at 6 TB/s — removing 40 % of its instructions
-// (the in-lane reset) changed nothing (measured: 345 us per launch at 4 M envs, in-lane 330-350).
-template <typename ST, int kMinWaves, int kTiles>
-__global__ __launch_bounds__(kBlock, kMinWaves) void step_kernel_fused(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
-                                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
-  StepArgs A = A_rest;   // the seven hot arguments are preloaded into SGPRs (see step_kernel)
-  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
-  __shared__ __attribute__((aligned(16))) float lds[kBlock * RDV_OBS_DIM];   // 17,408 B: wave-private staging regions
-  const DevParams& P = *Pp;   // scalar loads: see step_kernel
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave_in_block = threadIdx.x >> 6;
-  float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
-  const int64_t first = (((int64_t)blockIdx.x * (kBlock / kWave) + wave_in_block) * kTiles) * kWave;   // this wave's envs: [first, first + 64 kTiles)
-  TileIn<ST> cur;
-  tile_request<ST>(A, first, lane, cur);
-  if (kTiles == 1) {
-    tile_step<ST>(A, P, first, lane, wl, cur);
-    return;
-  }
-#pragma clang loop unroll(disable)
-  for (int j = 0; j < kTiles; ++j) {   // rolled: one copy of the tile code; the next tile's inputs travel while this one computes
-    int ln = lane;   // opaque copy: per-lane addresses are recomputed per tile instead of being kept in registers across the loop
-    asm volatile("" : "+v"(ln));
-    const int64_t base = first + (int64_t)j * kWave;
-    TileIn<ST> nxt = cur;
-    if (j + 1 < kTiles) tile_request<ST>(A, base + kWave, ln, nxt);
-    tile_step<ST>(A, P, base, ln, wl, cur);
-    cur = nxt;
-  }
-}
-
-// Refill of the marked slots.  One wave owns 1,024 consecutive envs: 16 tags per lane (4 x 16-byte loads), the marked ones are
-// compacted into a wave-private LDS list, and the whole reset runs once per 64 of them.
-constexpr int kRefillPerWave = 1024;
-template <typename ST>
-__global__ __launch_bounds__(kBlock) void refill_kernel(const DevParams* __restrict__ Pp, const StepArgs A) {
-  __shared__ uint16_t lists[kBlock / kWave][kRefillPerWave];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave_in_block = threadIdx.x >> 6;
-  uint16_t* list = lists[wave_in_block];
-  const int64_t base = ((int64_t)blockIdx.x * (kBlock / kWave) + wave_in_block) * kRefillPerWave;
-  const int64_t n = A.n;
-  if (base >= n) return;   // wave-uniform
-  int total = 0;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int first = (q * kWave + lane) * 4;     // this lane's four consecutive entries
-    uint32_t t[4] = {0u, 0u, 0u, 0u};
-    if (base + first + 3 < n && (n & 3) == 0) {
-      const uint4 v = *reinterpret_cast<const uint4*>(A.prep_tag + base + first);
-      t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
-    } else {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) if (base + first + c < n) t[c] = A.prep_tag[base + first + c];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const bool marked = (t[c] & kTagConsumed) != 0u;
-      const unsigned long long m = __ballot(marked);
-      if (marked) {
-        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        list[total + rank] = (uint16_t)(first + c);
-      }
-      total += __popcll(m);
-    }
-  }
-  wave_lds_fence();
-#pragma clang loop unroll(disable)
-  for (int j0 = 0; j0 < total; j0 += kWave) {
-    const int j = j0 + lane;
-    if (j < total) {
-      const int64_t i = base + list[j];
-      const uint32_t tag = A.prep_tag[i];
-      refill_whole<ST>(A, *Pp, i, tag & kTagMask, (tag & kTagTake) != 0u);
-    }
-  }
-}
-
-// Slots of all envs (after rdv_create + first reset they are written by reset_kernel; this kernel re-derives all of them from the
-// envs' current episode indices when something outside the step kernels changed what a reset returns: parameters, tape, restore,
-// or a launch of the in-lane kernels, which do not maintain them).
+// Slots of all envs, re-derived from the envs' current episode indices: run before a persistent kernel (rdv_step_many, rdv_rollout)
+// whenever something outside them changed what a reset returns (parameters, tape, seed, restore) or advanced episodes without
+// them (rdv_step: its kernels compute resets in registers and do not touch the slots).
 template <typename ST>
 __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __restrict__ Pp, const StepArgs A) {
   using V = typename Vec4<ST>::type;
@@ -596,165 +399,26 @@ __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __rest
 
 // ---------------------------------------------------------------------------------------------------------------
 // Split-role variant for a chip that is NOT full (N <= ~98k envs: one transition wave per SIMD): a 512-thread workgroup owns 256
-// envs.  Waves 0-3 ("step waves") do the whole transition for their 64 envs; a lane whose episode ends copies its prepared slot
-// and marks it (after the barrier).  Waves 4-7 ("service waves", one per SIMD beside a step wave) refill the slots the PREVIOUS
-// launch marked — typically 13 of the workgroup's 256 — while the step runs, sharing the work BY PART (wave 4: rc, vc + bookkeeping;
-// 5: qc, wc; 6: qt; 7: wt): every SIMD runs a ~300-instruction stream over the same compacted list instead of the whole
-// ~900-instruction reset for each of its 64 lanes (round 1).  One workgroup barrier: slots are refilled before it, marked after it.
-// An env that ends again in the launch that refills its slot (an episode of one step) takes the slot after the barrier.
+// envs.  Waves 0-3 ("step waves") do the whole transition for their 64 envs exactly as the fused kernel does, except the in-lane
+// reset.  Waves 4-7 ("service waves") run beside them — an 8-wave workgroup places waves w and w+4 on the same SIMD, so every SIMD
+// holds one of each — and compute every env's NEXT initial state and observation IN REGISTERS while the step runs (they depend only
+// on seed, env id and episode index).  After the single workgroup barrier a service lane whose env finished writes that state and
+// observation straight to HBM; the step waves have nothing left to do.  Same arithmetic, same results as the fused variant.
+// The next-state work is done for every env and used by ~5 %.  Round 2 built the alternative the first review asked for — the next
+// state persisted in HBM per env (rdv_slots.h), copied where an episode ends and refilled once per episode by compacted passes —
+// for this kernel and for the fused one, and measured it (profiles/r02_*): 8.2 us per launch against 7.3 for this form at 65,536
+// envs, 437 us against 317 at 4 M envs.  At one wave per SIMD the launch is a latency chain (1.2 us until the inputs are in, 1.9 us of
+// transition, ~1 us of outputs, ~1.6 us of launch boundary: tools/ubench_stream.hip measures 4.0 us for the bare stream and
+// boundary); the service waves' arithmetic runs in issue slots that are idle anyway and their results are in registers at the
+// barrier, whereas a slot has to be fetched (a dependent, sparse access) exactly on that chain.  When the chip is full the step is
+// bound by memory latency and request rate (59 % of the wave-cycles parked on s_waitcnt, profiles/r02_sq_counters_4M.csv), and
+// slots add ~600 B of sparse traffic per reset where the in-lane reset adds none.  The slots stay where they do pay: in LDS, inside
+// the persistent kernels (rdv_step_many.h, rdv_rollout.h).
 constexpr int kSplitEnvs = 256;      // envs per workgroup
 constexpr int kSplitBlock = 512;     // 8 waves
-constexpr int kSplitWaves = kSplitEnvs / kWave;
 
 template <typename ST>
 __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
-                                                       uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
-  StepArgs A = A_rest;   // the seven hot arguments are preloaded into SGPRs (see step_kernel)
-  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
-  using V = typename Vec4<ST>::type;
-  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // actions, then observation rows
-  __shared__ uint16_t job_list[kSplitWaves][kSplitEnvs];                             // wave-private lists of the service waves
-  __shared__ uint32_t job_counter[kSplitWaves][kSplitEnvs];
-  const DevParams& P = *Pp;   // scalar loads: see step_kernel
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wv = threadIdx.x >> 6;
-  const bool step_role = wv < kSplitWaves;
-  const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);
-  const int64_t block_base = (int64_t)blockIdx.x * kSplitEnvs;
-  const int64_t i = block_base + slot_in_block;
-  const int64_t wave_base = i - lane;
-  const int64_t n = A.n;
-  const bool active = i < n;
-  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
-  V* ws = reinterpret_cast<V*>(A.ws);
-  const bool resets = A.on_done == RDV_ON_DONE_RESET;
-  const SlotStore<ST> S = hbm_slots<ST>(A);
-  RDV_STAMP_DECL
-  RDV_STAMP(0);
-
-  if (step_role) {
-    // ------------------------------------------------------------------ step waves
-    float* wl = stage + wv * (kWave * RDV_OBS_DIM);
-    Env e;
-    StepResult r;
-    if (active) load_env<ST>(ws, n, i, e);
-    uint32_t tag = 0u;
-    if (resets && active) tag = A.prep_tag[i];
-    uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-    const uint64_t slot_pre = stats_preload(slot, lane);
-    float a[RDV_ACT_DIM];
-    load_actions(A.actions, wave_base, rows, lane, active, wl, a);
-#ifdef RDV_TOUCH
-    {   // the output pointers that are used only after the transition: fetched from the kernarg segment NOW, behind the state loads
-      const void *p1 = A.done, *p2 = A.terminal_obs, *p3 = A.episode_return, *p4 = A.episode_length, *p5 = A.done_reason;
-      asm volatile("" : : "s"(p1), "s"(p2), "s"(p3), "s"(p4), "s"(p5));
-    }
-#endif
-    RDV_STAMP(1);
-    const bool marked = (tag & kTagConsumed) != 0u;   // the service waves refill this slot during this launch
-    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
-    RDV_STAMP(2);
-    const bool fin = stepped && r.done;
-    const bool to_reset = fin && resets;
-    const bool take = to_reset && !marked;
-    const bool late = to_reset && marked;
-    const unsigned long long m_late = __ballot(late);
-    // (measured and dropped: requesting the slot ~150 instructions into the transition, where time-outs and bubble exits are already
-    //  decided — 8.46 us per launch against 8.22 at 65,536 envs: the 48 registers of the slot held across the transition cost more
-    //  than the ~0.4 us of load latency they hide.  Write-through `sc1` stores for state and rows, to spare the next launch the L2
-    //  write-back at the boundary: 10.8 us against 8.5.)
-    SlotRaw<ST> raw;
-#ifndef RDV_ABL_NOTAKE
-    if (take) slot_fetch<ST>(S, i, raw);      // 12 sparse 16-byte loads of one record, in flight during the statistics and the output stores
-#endif
-#ifndef RDV_ABL_NOSTATS
-    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-#endif
-#ifdef RDV_ABL_NOSPARSE
-    store_step_outputs<true>(A, i, active, false, r, e);
-#else
-    store_step_outputs<true>(A, i, active, fin, r, e);
-#endif
-    RDV_STAMP(3);
-#ifndef RDV_ABL_NOTAKE
-    if (take) slot_unpack<ST>(P, raw, e, r.obs);   // auto-reset (SB3 DummyVecEnv semantics): the first observation of the next episode
-#else
-    if (take) { e.k = 0; e.bubble = P.bubble_radius0; e.rc[1] = -10.0; e.rc[0] = 0.5; e.rc[2] = 0.1; e.vc[0] = e.vc[1] = e.vc[2] = 0.0; e.episode += 1u; }
-#endif
-    else if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-    // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores
-#pragma unroll
-    for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
-    wave_lds_fence();
-    if (m_late == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
-    RDV_STAMP(4);
-    if (stepped && !late) store_env<ST>(ws, n, i, e, take);   // 6 x 16-byte-per-lane stores (7 where a slot was taken)
-    RDV_STAMP(5);
-    __syncthreads();
-    RDV_STAMP(6);
-    // tags: this lane is the only writer of its env's tag in this launch
-    if (take) A.prep_tag[i] = e.episode | kTagConsumed;
-    else if (marked && !late) A.prep_tag[i] = (tag & kTagMask) + 1u;          // refilled before the barrier: clean again
-    if (m_late != 0ull) {   // wave-uniform, rare: an episode of a single step
-      if (late) {
-        slot_fetch<ST>(S, i, raw);            // written by the service waves of this workgroup before the barrier
-        slot_unpack<ST>(P, raw, e, r.obs);
-#pragma unroll
-        for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
-      }
-      wave_lds_fence();
-      store_obs_rows(A.obs, wave_base, rows, lane, wl);
-      if (late) {
-        store_env<ST>(ws, n, i, e, true);
-        A.prep_tag[i] = e.episode | kTagConsumed;
-      }
-    }
-  } else {
-    // ------------------------------------------------------------------ service waves
-    const int role = wv - kSplitWaves;
-    if (resets) {
-      bool pend[kSplitWaves];
-      uint32_t tg[kSplitWaves];
-#pragma unroll
-      for (int q = 0; q < kSplitWaves; ++q) {   // the tags of the workgroup's 256 envs, four per lane
-        const int64_t idx = block_base + q * kWave + lane;
-        tg[q] = idx < n ? A.prep_tag[idx] : 0u;
-        pend[q] = (tg[q] & kTagConsumed) != 0u;
-      }
-      RDV_STAMP(1);
-      const int total = compact_flags<kSplitWaves>(pend, lane, job_list[role]);
-      if (total > 0) {   // wave-uniform
-#pragma unroll
-        for (int q = 0; q < kSplitWaves; ++q)
-          if (pend[q]) job_counter[role][q * kWave + lane] = tg[q] & kTagMask;
-        wave_lds_fence();
-#pragma clang loop unroll(disable)
-        for (int j0 = 0; j0 < total; j0 += kWave) {
-          const int j = j0 + lane;
-          if (j < total) {
-            const int s = (int)job_list[role][j];
-            const uint32_t counter = job_counter[role][s];
-            const int64_t ii = block_base + s;
-            slot_refill_role<ST>(role, P, S, ii, A.seed, A.env_id_offset + (uint64_t)ii, counter, tape_row_of(A.tape, A.tape_depth, n, ii, counter));
-          }
-        }
-      }
-      RDV_STAMP(2);
-    }
-    RDV_STAMP(3);
-    __syncthreads();   // (release: the refilled parts are in memory before a step lane may take them)
-    RDV_STAMP(4);
-    RDV_STAMP(6);
-  }
-  RDV_STAMP(7);
-  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + wv)
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Round 1's split-role kernel ("next state beside the step"): waves 4-7 compute every env's next initial state and observation in
-// registers while waves 0-3 step; after the barrier a service lane whose env finished writes them.  No slots, no dependent loads.
-template <typename ST>
-__global__ __launch_bounds__(kSplitBlock) void step_kernel_split_r1(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
   // at wave launch (-mllvm -amdgpu-kernarg-preload-count=16) instead of being fetched from the host-visible kernarg
@@ -805,11 +469,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split_r1(void* ws_hot
 #pragma unroll
     for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
     wave_lds_fence();
-#ifdef RDV_R1_PATCH
-    store_obs_rows(A.obs, wave_base, rows, lane, wl);
-#else
     if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
-#endif
     RDV_STAMP(4);
     if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
     RDV_STAMP(5);
@@ -841,18 +501,11 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split_r1(void* ws_hot
       if (active && ((m_reset >> lane) & 1ull)) {
         // auto-reset (SB3 DummyVecEnv semantics): the new state to HBM, the first observation of the next episode into the row
         store_chunks<ST>(ws, n, i, packed, true);
-#ifdef RDV_R1_PATCH
-        float* row = A.obs + i * RDV_OBS_DIM;   // the step wave's block store has completed (its barrier's release): this lands last
-#pragma unroll
-        for (int j = 0; j < RDV_OBS_DIM; ++j) row[j] = robs[j];
-      }
-#else
 #pragma unroll
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
       }
       wave_lds_fence();
       store_obs_rows(A.obs, wave_base, rows, lane, wl);
-#endif
     }
     RDV_STAMP(6);
   }
@@ -1064,9 +717,6 @@ struct RdvEnvBatch {
   void* prep;        // prepared next-episode states (rdv_slots.h): records, tags
   uint32_t* prep_tag;
   bool prepared_ok;  // every slot holds what the env's next reset returns (false: prepare_kernel runs before the next slot-using launch)
-  bool tags_clean;   // no slot is marked "taken, refill pending" (step_kernel_split leaves marks for the next launch to refill)
-  int fused_min_waves;   // tuning: register budget of step_kernel_fused (2 or 3 waves per SIMD)
-  int fused_tiles;       // tuning: tiles per wave of step_kernel_fused (0: by batch size)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
 #endif
@@ -1086,8 +736,8 @@ static void base_args(const RdvEnvBatch* h, StepArgs& A) {
 }
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
 
-// The slot-using kernels (step_kernel_fused / _split, step_many_kernel, rollout_kernel) rely on every slot holding what the env's
-// next reset returns.  Whatever changes that from outside them (parameters, tape, restore, a launch of the in-lane kernels) clears
+// The persistent kernels (step_many_kernel, rollout_kernel) rely on every slot holding what the env's next reset returns.
+// Whatever changes that from outside them (parameters, tape, seed, restore) or advances episodes without them (rdv_step) clears
 // prepared_ok; the slots are then re-derived here, on the caller's stream, before the next such launch.
 static int ensure_prepared(RdvEnvBatch* h, hipStream_t s) {
   if (h->on_done != RDV_ON_DONE_RESET || h->prepared_ok) return RDV_OK;
@@ -1096,20 +746,7 @@ static int ensure_prepared(RdvEnvBatch* h, hipStream_t s) {
   if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(prepare_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, A);
   else hipLaunchKernelGGL(prepare_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev_params, A);
   RDV_HIP(hipGetLastError());
-  h->prepared_ok = true; h->tags_clean = true;
-  return RDV_OK;
-}
-// refill_kernel: every marked slot is refilled (the fused step kernel starts from clean slots and is followed by this)
-static int refill_marked(RdvEnvBatch* h, hipStream_t s, float* obs) {
-  StepArgs A;
-  base_args(h, A);
-  A.obs = obs;
-  const int64_t per_block = (int64_t)kRefillPerWave * (kBlock / kWave);
-  const dim3 grid((unsigned)((h->n + per_block - 1) / per_block));
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(refill_kernel<float>, grid, dim3(kBlock), 0, s, h->dev_params, A);
-  else hipLaunchKernelGGL(refill_kernel<double>, grid, dim3(kBlock), 0, s, h->dev_params, A);
-  RDV_HIP(hipGetLastError());
-  h->tags_clean = true;
+  h->prepared_ok = true;
   return RDV_OK;
 }
 // the derived parameter block -> device, ordered on `s` (params_kernel)
@@ -1319,7 +956,6 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(rollout_kernel<float>, grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
   else hipLaunchKernelGGL(rollout_kernel<double>, grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
   RDV_HIP(hipGetLastError());
-  h->tags_clean = true;   // the persistent kernels refill marked slots before their first use and hand every slot back clean
   return RDV_OK;
 }
 
@@ -1356,9 +992,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->acos_table = reinterpret_cast<double*>(reinterpret_cast<char*>(h->dev_params) + params_bytes());
   h->prep = reinterpret_cast<char*>(h->acos_table) + acos_bytes();
   h->prep_tag = reinterpret_cast<uint32_t*>(static_cast<char*>(h->prep) + prep_bytes(n_envs, storage));
-  h->prepared_ok = false; h->tags_clean = true; h->fused_min_waves = 2; h->fused_tiles = 0;
-  if (const char* v = std::getenv("RDV_FUSED_MIN_WAVES")) h->fused_min_waves = std::atoi(v) == 3 ? 3 : 2;   // tuning knobs
-  if (const char* v = std::getenv("RDV_FUSED_TILES")) { const int t = std::atoi(v); h->fused_tiles = (t == 1 || t == 2 || t == 4) ? t : 0; }
+  h->prepared_ok = false;
   h->dev.acos_table = h->acos_table;
   // every step of the set-up reports itself: which call failed, and why
   const char* what = "hipMemset of the workspace";
@@ -1504,7 +1138,7 @@ int rdv_debug_set_stamps(rdv_handle h, unsigned long long* stamps) {   // diagno
 #endif
 int rdv_set_kernel_variant(rdv_handle h, int variant) {
   RDV_CHECK_HANDLE(h);
-  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT && variant != RDV_VARIANT_INLANE && variant != RDV_VARIANT_SPLIT_R1)
+  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_kernel_variant: bad variant %d", variant);
   h->variant = variant;
   return RDV_OK;
@@ -1552,46 +1186,18 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   A.stamps = h->stamps;
 #endif
   hipStream_t s = static_cast<hipStream_t>(stream);
-  // Cold configurations run on the in-lane kernel (step_kernel): evaluator diagnostics, general rigid bodies (their integrator is a
-  // per-lane adaptive loop), the first step after rdv_set_state (kRaw), or when asked for (RDV_VARIANT_INLANE).
+  // general rigid bodies run on the fused layout only (their integrator is a per-lane adaptive loop: no fixed phase to split), as do
+  // the evaluator-diagnostics build and the first step after rdv_set_state (kRaw)
   const bool raw = h->raw_state && !h->general;   // (the RK45 kernels integrate the quaternion as given, like the reference)
   h->raw_state = false;
-  const bool inlane = A.diag || h->general || raw || h->variant == RDV_VARIANT_INLANE;
-  if (!inlane && h->variant == RDV_VARIANT_SPLIT_R1) {
-    const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
-    if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL((step_kernel_split_r1<float>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
-    else hipLaunchKernelGGL((step_kernel_split_r1<double>), grid, block, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A);
-    if (h->on_done == RDV_ON_DONE_RESET) h->prepared_ok = false;
-    RDV_HIP(hipGetLastError());
-    return RDV_OK;
-  }
+  const bool split = !A.diag && !h->general && !raw && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
 #define RDV_LAUNCH(KERNEL, GRID, BLOCK) hipLaunchKernelGGL((KERNEL), GRID, BLOCK, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A)
-  if (!inlane) {
-    if (int rc = ensure_prepared(h, s)) return rc;
-    const bool split = h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs);
-    const bool resets = h->on_done == RDV_ON_DONE_RESET;
-    if (split) {
-      const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
-      if (h->storage == RDV_STORAGE_F32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
-      if (resets) h->tags_clean = false;   // the slots taken in this launch are refilled by the next one
-    } else {
-      if (resets && !h->tags_clean) { if (int rc = refill_marked(h, s, A.obs)) return rc; }
-      // tiles of 64 envs per wave (software-pipelined): as many as leave >= ~6 waves per SIMD in the grid
-      const int64_t tiles = (h->n + kWave - 1) / kWave;
-      int per_wave = h->fused_tiles > 0 ? h->fused_tiles : (tiles >= 32768 ? 4 : (tiles >= 12288 ? 2 : 1));
-      if (h->storage == RDV_STORAGE_F64) per_wave = 1;   // (parity mode: a second set of 64-byte-per-lane inputs does not fit the registers)
-      const int64_t per_block = (int64_t)kBlock * per_wave;
-      const dim3 grid((unsigned)((h->n + per_block - 1) / per_block)), block(kBlock);
-      const bool f32 = h->storage == RDV_STORAGE_F32;
-      if (!f32) RDV_LAUNCH((step_kernel_fused<double, 3, 1>), grid, block);
-      else if (per_wave == 1) RDV_LAUNCH((step_kernel_fused<float, 3, 1>), grid, block);
-      else if (h->fused_min_waves == 3) { if (per_wave == 4) RDV_LAUNCH((step_kernel_fused<float, 3, 4>), grid, block); else RDV_LAUNCH((step_kernel_fused<float, 3, 2>), grid, block); }
-      else { if (per_wave == 4) RDV_LAUNCH((step_kernel_fused<float, 2, 4>), grid, block); else RDV_LAUNCH((step_kernel_fused<float, 2, 2>), grid, block); }
-      if (resets) { if (int rc = refill_marked(h, s, A.obs)) return rc; }
-    }
+  const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr;
+  if (split) {
+    const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
+    if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
   } else {
     const dim3 grid = grid_for(h->n), block(kBlock);
-    const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr;
     if (h->general) {
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false, true>), grid, block); }
       else { if (dg) RDV_LAUNCH((step_kernel<double, true, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false, true>), grid, block); }
@@ -1602,10 +1208,10 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false>), grid, block); }
       else { if (dg) RDV_LAUNCH((step_kernel<double, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false>), grid, block); }
     }
-    if (h->on_done == RDV_ON_DONE_RESET) h->prepared_ok = false;   // the in-lane kernel resets without the slots: they lag behind now
   }
 #undef RDV_LAUNCH
   RDV_HIP(hipGetLastError());
+  if (h->on_done == RDV_ON_DONE_RESET) h->prepared_ok = false;   // the step kernels reset in registers: the slots of the persistent kernels lag behind now
   return RDV_OK;
 }
 
@@ -1634,7 +1240,6 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(step_many_kernel<float>, grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
   else hipLaunchKernelGGL(step_many_kernel<double>, grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
   RDV_HIP(hipGetLastError());
-  h->tags_clean = true;   // (as rdv_rollout)
   return RDV_OK;
 }
 

@@ -2,44 +2,32 @@
 // env's NEXT episode, computed ahead of time and kept until the episode ends.
 //
 // A reset depends only on (seed, global env id, episode index) — or on a row of the reset tape — so it can be computed any time
-// before it is needed.  Round 1 computed it for every env in every launch (service waves) or in-lane where an episode ended
-// (divergent: ~96 % of the waves ran the ~900-instruction reset for ~5 % of their lanes).  Now every env owns a slot in HBM, one
-// record per env:
+// before it is needed.  The persistent kernels (rdv_step_many.h, rdv_rollout.h) keep one slot per env:
 //     7 state chunks in storage layout (the state reset() produces, bookkeeping included: t = 0, bubble_radius0, totals 0,
-//     collided / success of the initial state, episode index + 1)  +  its observation (17 floats in 5 float4)  +  a tag.
-// A lane whose episode ends COPIES its slot (12 sparse 16-byte loads, issued while the episode statistics are reduced) instead of
-// computing anything; the slot is then refilled for the following episode, once, by compacted passes over the few envs of a
-// workgroup that need it:
-//   - step_kernel_fused (chip full): after the workgroup's stores, one wave runs the whole reset for the <= 64 listed envs;
-//   - step_kernel_split / step_many_kernel / rollout_kernel (one transition wave per SIMD): the refill is left to the NEXT launch
-//     / step and shared out over the four SIMDs BY PART (rc+vc | qc+wc | qt | wt: reset_fields<ST, kPart>), so that no SIMD
-//     runs more than a ~300-instruction stream beside its transition wave.
-// tag[i] = (episode index the slot's state carries, i.e. the index of the episode it starts, + 1 ... see below) | kTagConsumed:
-//   clean  : tag == e.episode + 1   — the slot holds reset(seed, id, counter = e.episode), whose own episode field is e.episode + 1
-//   marked : tag & kTagConsumed     — the slot was copied into the env by a launch that leaves the refill to the next launch;
-//            (tag & kTagMask) == e.episode is the counter to refill it with.  With kTagTake as well (step_kernel_fused hands the
-//            copy itself to refill_kernel, launched right behind it): the env has ended its episode and still waits for the slot.
-// Results are bit-identical to the in-lane reset (same expressions on the same inputs); every equality test of round 1 holds.
+//     collided / success of the initial state, episode index + 1)  +  its observation (17 floats in 5 float4)
+// in LDS for the duration of a launch (struct-of-arrays, conflict-free) and in HBM between launches (one record per env + a tag).
+// A lane whose episode ends COPIES its slot instead of computing anything; the slot is then refilled for the following episode,
+// once, by the waves that would otherwise idle, sharing the work BY PART (rc+vc | qc+wc | qt | wt: reset_fields<ST, kPart>) over a
+// compacted list of the ~13 of 256 envs that need it: a ~300-instruction stream per SIMD and step where round 1 ran the whole
+// ~900-instruction reset for every lane (service waves) or in ~96 % of the env waves (in-lane, divergent).
+// tag[i] == e.episode + 1 says that env i's slot in HBM holds reset(seed, id, counter = e.episode) (whose own episode field is
+// e.episode + 1); anything else is refilled before its first use.
+// Results are bit-identical to the in-lane reset (same expressions on the same inputs).
+// (The one-launch step kernels do NOT use slots: measured, round 2 — see step_kernel_split in rdv_hip.hip.)
 #pragma once
 
 namespace rdv {
 
-constexpr uint32_t kTagConsumed = 0x80000000u;
-constexpr uint32_t kTagTake = 0x40000000u;       // (with kTagConsumed, step_kernel_fused -> refill_kernel) the env has yet to take the slot
-constexpr uint32_t kTagMask = ~(kTagConsumed | kTagTake);
 constexpr int kSlotObsVecs = 5;            // 17 observation floats in 5 float4 (3 pad)
-enum : uint32_t { JOB_NONE = 0, JOB_REFILL = 1, JOB_FALLBACK = 2 };
+enum : uint32_t { JOB_NONE = 0, JOB_REFILL = 1 };
 // flags word of a slot that was refilled by part and whose state lies close enough to the target for collided / success (:261-262)
 // to be possibly non-zero: they need the whole state, so the lane that takes the slot evaluates them (never with the reference's
 // nominal start 10 m out; keeps the whole-state arithmetic out of the refilling waves)
 constexpr uint32_t kFlagsPending = 0xFFFFFFFFu;
 
 // Slot storage: chunk c of entry i at chunks[c * cs + i * es], observation vector v at obs[v * ocs + i * oes].
-//   HBM (hbm_slot_store): ONE RECORD PER ENV — 7 chunks then 5 observation vectors, 192 B (float) / 320 B (double, padded) — because
-//   slots are touched sparsely (the ~5 % of envs whose episode ended): a record is 2-3 cache lines and one page, where the
-//   struct-of-arrays form of the first version cost 12 lines in 12 arrays per env (measured at 4 M envs: the step kernel 414 us
-//   against 332 us for the in-lane reset it replaced, the refill 103 us, both bound by those 16-byte accesses).
-//   LDS (persistent kernels keep their workgroup's slots there): struct-of-arrays, conflict-free 16-byte accesses.
+//   HBM (hbm_slot_store): one record per env — 7 chunks then 5 observation vectors, 192 B (float) / 320 B (double, padded).
+//   LDS (the persistent kernels keep their workgroup's slots there): struct-of-arrays, conflict-free 16-byte accesses.
 template <typename ST>
 struct SlotStore {
   typename Vec4<ST>::type* chunks;

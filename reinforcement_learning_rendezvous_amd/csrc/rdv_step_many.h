@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     if (resets) {
       uint32_t tag = 0u;
       if (active) { tag = A.prep_tag[i]; slot_copy<ST>(L, slot, H, i); }
-      const bool stale = active && tag != e.episode + 1u;    // left marked by a step_kernel_split launch: refilled before the first use
+      const bool stale = active && tag != e.episode + 1u;    // not current (cannot happen behind ensure_prepared; kept as a guard): refilled before its first use
       job_kind[slot] = stale ? JOB_REFILL : JOB_NONE;
       job_counter[slot] = e.episode;
       slot_dirty = stale;

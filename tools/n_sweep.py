@@ -17,8 +17,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--storage", default="f32")
     ap.add_argument("--sizes", default="4096,16384,65536,131072,262144,524288,1048576,4194304,16777216")
-    ap.add_argument("--variants", default="split,fused,inlane",
-                    help="split | fused[:tiles per wave[:waves per SIMD]] (tuning knobs RDV_FUSED_TILES, RDV_FUSED_MIN_WAVES) | inlane (round 1's layout)")
+    ap.add_argument("--variants", default="split,fused")
     args = ap.parse_args()
     import torch
     from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
@@ -29,10 +28,7 @@ def main():
         for variant in args.variants.split(","):
             if variant == "split" and n > 1048576:
                 continue
-            parts = variant.split(":")
-            os.environ["RDV_FUSED_TILES"] = parts[1] if len(parts) > 1 else "0"
-            os.environ["RDV_FUSED_MIN_WAVES"] = parts[2] if len(parts) > 2 else "2"
-            env = RendezvousBatch(n, device="cuda:0", storage=args.storage, seed=0, variant=parts[0])
+            env = RendezvousBatch(n, device="cuda:0", storage=args.storage, seed=0, variant=variant)
             env.reset()
             for t in range(16):
                 env.step(acts[t % 4])
