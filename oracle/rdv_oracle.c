@@ -35,9 +35,13 @@ int64_t orc_sizeof_params(void) { return (int64_t)sizeof(OrcParams); }
 static const double ORC_PI = 3.14159265358979323846;
 
 static double radians(double deg) { return deg * (ORC_PI / 180.0); } /* np.radians */
-static double norm3(const double v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
-static double norm4(const double q[4]) { return sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]); }
-static double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+/* np.linalg.norm(v) of a 1-D float64 array is sqrt(v.dot(v)), and v.dot(v) / np.dot(a, b) go to the BLAS ddot: with the NumPy the golden
+ * vectors were recorded under (2.2.6, bundled OpenBLAS) that is the ascending chain of fused multiply-adds below for 3 and 4
+ * elements — verified on 20,000 random vectors each, bit for bit, and pinned by tests/golden/boundary_diag.npz, where a norm sits
+ * 0-2 ulp from a limit.  (A BLAS without FMA sums rounded products: the comparisons then fall differently in ~1 of 10^15 states.) */
+static double norm3(const double v[3]) { return sqrt(fma(v[2], v[2], fma(v[1], v[1], v[0] * v[0]))); }
+static double norm4(const double q[4]) { return sqrt(fma(q[3], q[3], fma(q[2], q[2], fma(q[1], q[1], q[0] * q[0])))); }
+static double dot3(const double a[3], const double b[3]) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
 static void cross3(const double a[3], const double b[3], double c[3]) {
   c[0] = a[1] * b[2] - a[2] * b[1];
   c[1] = a[2] * b[0] - a[0] * b[2];

@@ -49,7 +49,11 @@ struct DevParams {
   double inv_max_attitude_error, inv_max_rd_error, inv_max_qd_error;
   double corridor_axis[3], capture_axis[3], rd[3];
   double inv_corridor_norm, inv_capture_norm;
-  double max_rd_error2, max_vd_error2, max_wd_error2;   // squared limits (:105-108)
+  // The reference compares NORMS with limits: np.linalg.norm(x) <= limit (:416-417), < limit (:348, :397).  The kernel keeps the
+  // sum of squares s (formed as the reference's NumPy forms it: sumsq3) and compares it with
+  // the largest double T for which sqrt(T) <= limit (le2_*) or sqrt(T) < limit (lt2_*), found on the host with the correctly rounded
+  // sqrt: since sqrt is monotone, s <= T decides exactly what sqrt(s) <= limit decides — no sqrt, and no off-by-an-ulp of limit^2.
+  double le2_rd, lt2_rd, le2_vd, le2_wd, lt2_koz;
   // thresholds on k = rint(1e5*cos) equivalent to the reference's tests on acos(round(cos,5)) (general.py:179)
   double reset_flag_radius2;            // (max(koz_radius, |rd| + max_rd_error))^2: beyond it a fresh state has collided = success = 0
   double kc_coll_max;                   // in corridor cone test (:401): angle > half_angle      <=> k <= kc_coll_max
@@ -81,9 +85,9 @@ struct Env {
 
 // What the flags / reward / done / diagnostics need from the (canonical) state.
 struct Derived {
-  double dist;              // |rc|
+  double r2;                // |rc|^2, NumPy's sum of squares
   double k_att, k_corr;     // rint(1e5 * cos) of the attitude error (:432) and of the corridor angle (:400)
-  double pos2, vel2, rot2;  // squared get_errors() entries (:463-466)
+  double pos2, vel2, rot2;  // squared get_errors() entries (:463-466), NumPy's sums of squares
 };
 
 __device__ __forceinline__ double canon(double x, float) { return (double)(float)x; }
@@ -105,6 +109,9 @@ __device__ __forceinline__ double rsqrt64(double x) {
 }
 
 __device__ __forceinline__ double dot3(const double* a, const double* b) { return fma(a[2], b[2], fma(a[1], b[1], a[0] * b[0])); }
+// np.linalg.norm(v)**2 before the square root: v.dot(v) as the BLAS of the reference's NumPy forms it for three elements — this
+// same ascending chain of fused multiply-adds (oracle/rdv_oracle.c, norm3; pinned by tests/golden/boundary_diag.npz)
+__device__ __forceinline__ double sumsq3(const double* v) { return dot3(v, v); }
 
 // cos(t) and sin(t)/t from u = t*t, for u <= kSmallU (t <= ~pi/4): Taylor to u^9, truncation < 2e-18
 constexpr double kSmallU = 0.62;
@@ -347,9 +354,9 @@ __device__ __forceinline__ void derive_chaser(const DevParams& P, const Env& e, 
   quat2mat(e.qc, Rc);
   double cap_l[3];
   matvec(Rc, P.capture_axis, cap_l);    // :431
-  const double r2 = dot3(e.rc, e.rc);
+  const double r2 = sumsq3(e.rc);
   inv_dist = rsqrt64(r2);
-  d.dist = r2 * inv_dist;
+  d.r2 = r2;
   // general.py:179: round(cos, 5) == rint(cos*1e5)/1e5; rotations preserve |capture_axis|, |corridor_axis|
   d.k_att = rint(-dot3(e.rc, cap_l) * (inv_dist * P.inv_capture_norm) * 1e5);           // :432
 }
@@ -360,10 +367,10 @@ __device__ __forceinline__ void derive_target(const DevParams& P, const Env& e, 
   double rd_l[3];
   matvec(Rt, P.rd, rd_l);               // :460
   const double dp[3] = {e.rc[0] - rd_l[0], e.rc[1] - rd_l[1], e.rc[2] - rd_l[2]};
-  d.pos2 = dot3(dp, dp);                // :463
+  d.pos2 = sumsq3(dp);                  // :463
   const double inf = __builtin_huge_val();
   d.vel2 = inf; d.rot2 = inf; d.k_corr = inf;
-  if (!kLazy || d.pos2 <= P.max_rd_error2) {
+  if (!kLazy || d.pos2 <= P.le2_rd) {
     double wc_l[3], wt_l[3];
     matvec(Rc, e.wc, wc_l);             // :458
     matvec(Rt, e.wt, wt_l);             // :459
@@ -371,10 +378,10 @@ __device__ __forceinline__ void derive_target(const DevParams& P, const Env& e, 
                             fma(wt_l[0], rd_l[1], -wt_l[1] * rd_l[0])};                 // :461
     const double dv[3] = {e.vc[0] - vd_l[0], e.vc[1] - vd_l[1], e.vc[2] - vd_l[2]};
     const double dw[3] = {wc_l[0] - wt_l[0], wc_l[1] - wt_l[1], wc_l[2] - wt_l[2]};
-    d.vel2 = dot3(dv, dv);              // :464
-    d.rot2 = dot3(dw, dw);              // :466
+    d.vel2 = sumsq3(dv);                // :464
+    d.rot2 = sumsq3(dw);                // :466
   }
-  if (!kLazy || d.dist < P.koz_radius) {
+  if (!kLazy || d.r2 <= P.lt2_koz) {
     double corr_l[3];
     matvec(Rt, P.corridor_axis, corr_l);                                                // :400
     d.k_corr = rint(dot3(e.rc, corr_l) * (inv_dist * P.inv_corridor_norm) * 1e5);
@@ -405,16 +412,16 @@ __device__ __forceinline__ double attitude_error_of(const DevParams& P, double k
 
 // check_collision (:388-404)
 __device__ __forceinline__ bool in_koz(const DevParams& P, const Derived& d) {
-  return d.dist < P.koz_radius && d.k_corr <= P.kc_coll_max;
+  return d.r2 <= P.lt2_koz && d.k_corr <= P.kc_coll_max;       // norm(rc) < koz_radius (:397)
 }
 // np.all(errors <= error_ranges) (:416-417)
 __device__ __forceinline__ bool errors_ok(const DevParams& P, const Derived& d) {
-  return d.pos2 <= P.max_rd_error2 && d.vel2 <= P.max_vd_error2 && d.k_att >= P.ka_succ_min && d.rot2 <= P.max_wd_error2;
+  return d.pos2 <= P.le2_rd && d.vel2 <= P.le2_vd && d.k_att >= P.ka_succ_min && d.rot2 <= P.le2_wd;
 }
 
 // dist_from_koz (:510-537) — evaluator-only
 __device__ __forceinline__ double dist_from_koz(const DevParams& P, const Derived& d) {
-  const double pos_mag = d.dist, r_koz = P.koz_radius, th_c = P.corridor_half_angle;
+  const double pos_mag = sqrt(d.r2), r_koz = P.koz_radius, th_c = P.corridor_half_angle;   // np.linalg.norm (:519)
   const double th = angle_of(d.k_corr);
   const double pi_2 = 1.57079632679489661923;
   double out;
@@ -709,14 +716,19 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   bool outside = false;
 #pragma unroll
   for (int i = 0; i < 17; ++i) outside |= !(fabsf(r.obs[i]) <= 1.0f);                  // Box.contains; NaN -> outside
-  const bool c_time = e.k >= P.k_time, c_bubble = d.dist > e.bubble, c_att = d.k_att <= P.ka_done_max;
+  // norm(rc) > bubble_radius (:369): the bubble changes every step, so the sum of squares is compared with bubble^2 bracketed by its
+  // rounding, and the correctly rounded square root decides inside the bracket (one wave in ~10^14 goes there)
+  const double b2 = e.bubble * e.bubble;
+  bool c_bubble = d.r2 > b2 * (1.0 + 1e-15);
+  if (__builtin_expect(!c_bubble && d.r2 > b2 * (1.0 - 1e-15), 0)) c_bubble = sqrt(d.r2) > e.bubble;
+  const bool c_time = e.k >= P.k_time, c_att = d.k_att <= P.ka_done_max;
   r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
   r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
   // :313-353
   double rew = P.att_term * fma(-att, P.inv_max_attitude_error, 1.0);                  // :329
   rew += (double)(mul_f32_rn(P.fuel_scale_f32, sum_v) / P.fuel_div_f32);               // :333
   if (inst_coll) rew -= P.coll_term;                                                   // :336-337
-  if (d.dist < P.koz_radius && !(e.flags & FLAG_COLLIDED) && d.pos2 < P.max_rd_error2) {   // :340, :348
+  if (d.r2 <= P.lt2_koz && !(e.flags & FLAG_COLLIDED) && d.pos2 <= P.lt2_rd) {             // :340, :348 (both strict: lt2_*)
     rew += P.bonus_term * fma(-sqrt(d.pos2), P.inv_max_rd_error, 2.0);                 // :349
     if (d.k_att >= P.ka_bonus_min) rew += P.bonus_term * fma(-att, P.inv_max_qd_error, 2.0);   // :350-351
   }

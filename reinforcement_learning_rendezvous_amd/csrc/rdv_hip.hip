@@ -634,6 +634,19 @@ static double largest_k_with_angle_above(double theta, bool strict) {
 
 static inline double norm3h(const double* v) { return std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
 
+// Largest double T >= 0 with sqrt(T) <= limit (strict: sqrt(T) < limit), -1 if there is none: T decides, for a sum of squares s,
+// exactly what the reference's `np.linalg.norm(x) <= limit` decides for sqrt(s) (std::sqrt is correctly rounded, as NumPy's).
+static double sq_threshold(double limit, bool strict) {
+  auto ok = [&](double v) { const double r = std::sqrt(v); return strict ? r < limit : r <= limit; };
+  if (limit != limit || !ok(0.0)) return -1.0;
+  if (std::isinf(limit)) return strict ? 1.79769313486231570815e308 : limit;
+  double x = limit * limit;
+  if (std::isinf(x)) x = 1.79769313486231570815e308;
+  while (x > 0.0 && !ok(x)) x = std::nextafter(x, 0.0);
+  while (x < 1.79769313486231570815e308 && ok(std::nextafter(x, INFINITY))) x = std::nextafter(x, INFINITY);
+  return x;
+}
+
 static void derive_params(const RdvParams& p, DevParams& d) {
   std::memset(&d, 0, sizeof d);
   const double n = p.n, t = p.dt, nt = n * t, c = std::cos(nt), s = std::sin(nt);
@@ -662,7 +675,9 @@ static void derive_params(const RdvParams& p, DevParams& d) {
   d.inv_max_attitude_error = 1.0 / p.max_attitude_error; d.inv_max_rd_error = 1.0 / p.max_rd_error; d.inv_max_qd_error = 1.0 / p.max_qd_error;
   for (int i = 0; i < 3; ++i) { d.corridor_axis[i] = p.corridor_axis[i]; d.capture_axis[i] = p.capture_axis[i]; d.rd[i] = p.rd[i]; }
   d.inv_corridor_norm = 1.0 / norm3h(p.corridor_axis); d.inv_capture_norm = 1.0 / norm3h(p.capture_axis);
-  d.max_rd_error2 = p.max_rd_error * p.max_rd_error; d.max_vd_error2 = p.max_vd_error * p.max_vd_error; d.max_wd_error2 = p.max_wd_error * p.max_wd_error;
+  d.le2_rd = sq_threshold(p.max_rd_error, false); d.lt2_rd = sq_threshold(p.max_rd_error, true);        // :416 (<=), :348 (<)
+  d.le2_vd = sq_threshold(p.max_vd_error, false); d.le2_wd = sq_threshold(p.max_wd_error, false);       // :416-417
+  d.lt2_koz = sq_threshold(p.koz_radius, true);                                                        // :397, :340
   {  // an initial state can only be inside the KOZ sphere or meet the capture position error within this radius of the target
     const double rr = std::fmax(p.koz_radius, norm3h(p.rd) + p.max_rd_error) * (1.0 + 1e-9);
     d.reset_flag_radius2 = rr * rr;

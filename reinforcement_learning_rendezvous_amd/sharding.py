@@ -4,8 +4,8 @@ Multi-GPU sharding of the env batch: one process per GPU, envs partitioned by co
 The reference has no distributed code at all; envs are independent units, so ``step()``/``reset()`` need NO
 collective: rank g owns envs [g*N/W, (g+1)*N/W) and keys its reset RNG by GLOBAL env id, so results do not depend on the
 shard count.  Collectives exist only where data really has to move:
-  - ``gather_rollout``  : obs / reward / done of one step to rank 0 for a single learner (RCCL gather over xGMI —
-                          7 concurrent peer->rank0 transfers on a fully connected node, not a ring);
+  - ``RolloutGather``   : obs / reward / done of one step to rank 0 for a single learner, ONE packed [n,19] message per rank
+                          (RCCL gather over xGMI — 7 concurrent peer->rank0 transfers on a fully connected node, not a ring);
   - ``reduce_stats``    : the ~12 episode-statistics scalars (one small all-reduce);
   - ``gather_columns``  : Monte Carlo result columns to rank 0.
 ``torch.distributed`` must already be initialised (backend "nccl" = RCCL on GPUs, "gloo" in the CPU tests).
@@ -26,7 +26,9 @@ def shard_range(n_global, rank, world):
 
 
 def make_shard(n_global, rank=None, world=None, engine_cls=None, **kw):
-    """This rank's shard of a global batch of ``n_global`` envs (env_id_offset = first owned global index)."""
+    """This rank's shard of a global batch of ``n_global`` envs (env_id_offset = first owned global index).  Shard sizes differ
+    by one env when ``n_global`` is not a multiple of the number of ranks: fine for step()/reset() (no collective), refused by
+    RolloutGather (a gather needs equal sizes)."""
     rank = dist.get_rank() if rank is None else rank
     world = dist.get_world_size() if world is None else world
     lo, hi = shard_range(n_global, rank, world)
@@ -35,18 +37,53 @@ def make_shard(n_global, rank=None, world=None, engine_cls=None, **kw):
     return engine_cls(hi - lo, env_id_offset=lo, **kw), (lo, hi)
 
 
-def gather_rollout(tensors, dst=0):
-    """Gather equally sized per-rank tensors (e.g. obs [n,17], reward [n], done [n]) to ``dst``.
+ROLLOUT_WIDTH = 19     # one row per env and step: 17 observation floats, the reward, done (0.0 / 1.0)
 
-    Returns the concatenation along dim 0 on ``dst`` (rank order = global env order) and None elsewhere."""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    out = []
-    for t in tensors:
-        t = t.contiguous()
-        bufs = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-        dist.gather(t, bufs, dst=dst)
-        out.append(torch.cat(bufs, dim=0) if rank == dst else None)
-    return out if rank == dst else None
+
+class RolloutGather:
+    """One step's rollout rows (obs [n,17], reward [n], done [n]) of every rank to ``dst`` as ONE message per rank.
+
+    Each rank packs its rows into one contiguous float32 tensor [n, 19]; ``dst`` receives them straight into consecutive
+    row blocks of one preallocated [world * n, 19] buffer (rank order = global env order: no concatenation, no second copy).
+    On a fully connected xGMI node the 7 peer -> dst transfers each use their own link; the message is 4.98 MB per rank at
+    65,536 envs.  All shards must hold the same number of envs (checked once, here): RCCL's gather has no way to say otherwise
+    and would hang or corrupt the rows.  ``torch.distributed`` must be initialised (backend "nccl" = RCCL, "gloo" in CPU tests)."""
+
+    def __init__(self, n_local, device, dst=0):
+        self.world, self.rank, self.dst, self.n = dist.get_world_size(), dist.get_rank(), int(dst), int(n_local)
+        sizes = torch.tensor([self.n], dtype=torch.int64, device=device)
+        all_sizes = [torch.zeros_like(sizes) for _ in range(self.world)]
+        dist.all_gather(all_sizes, sizes)
+        if any(int(x.item()) != self.n for x in all_sizes):
+            raise ValueError(f"RolloutGather needs equally sized shards, got {[int(x.item()) for x in all_sizes]} "
+                             "(make the global env count a multiple of the number of ranks)")
+        self.local = torch.empty((self.n, ROLLOUT_WIDTH), dtype=torch.float32, device=device)
+        self.full = torch.empty((self.world * self.n, ROLLOUT_WIDTH), dtype=torch.float32, device=device) if self.rank == self.dst else None
+        self.blocks = list(self.full.split(self.n, dim=0)) if self.full is not None else None   # views, not copies
+
+    def pack(self, obs, reward, done):
+        self.local[:, :17].copy_(obs)
+        self.local[:, 17].copy_(reward)
+        self.local[:, 18].copy_(done)           # uint8 -> 0.0 / 1.0
+        return self.local
+
+    def gather(self, obs, reward, done):
+        """Returns (obs [W*n,17], reward [W*n], done [W*n] as float 0/1) views of the gathered buffer on ``dst``, None elsewhere."""
+        dist.gather(self.pack(obs, reward, done), self.blocks, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        return self.full[:, :17], self.full[:, 17], self.full[:, 18]
+
+
+def gather_rollout(tensors, dst=0):
+    """obs [n,17], reward [n], done [n] of every rank -> the global arrays on ``dst`` (rank order = global env order), None
+    elsewhere; one message per rank (RolloutGather).  For repeated use keep a RolloutGather: it owns the buffers."""
+    obs, reward, done = tensors
+    g = RolloutGather(obs.shape[0], obs.device, dst=dst)
+    out = g.gather(obs, reward, done)
+    if out is None:
+        return None
+    return [out[0], out[1], out[2].to(torch.uint8)]
 
 
 def reduce_stats(stats, device=None):

@@ -72,9 +72,15 @@ _DIAG_METHODS = {"get_errors": slice(0, 4), "get_attitude_error": 2, "check_coll
 
 class RendezvousVecEnv(_VecEnvBase):
     def __init__(self, num_envs, device="cuda:0", storage="f32", seed=0, quiet=True, params=None, engine=None,
-                 **env_kwargs):
+                 copy_outputs=False, gc_freeze=True, **env_kwargs):
         """``env_kwargs``: the reference constructor's keyword arguments (rendezvous_env.py:17-37), shared by all envs.
-        ``engine``: an already constructed batch (tests inject a CPU-oracle-backed one; the product default is HIP)."""
+        ``engine``: an already constructed batch (tests inject a CPU-oracle-backed one; the product default is HIP).
+        ``copy_outputs``: return fresh obs / reward arrays every step, as SB3's DummyVecEnv does; by default they are views of one
+        reused host buffer that the next step overwrites (SB3's rollout buffer copies what it is given).
+        ``gc_freeze``: call ``gc.freeze()`` once here.  Every step creates a few thousand short-lived ``infos`` dicts (one per finished
+        env), which makes CPython's cyclic collector run a full collection every few steps; each one walks every object the process
+        has alive — with torch imported ~38 ms, against ~1.3 ms for a step (tools/vecenv_profile.py).  Freezing moves what exists now
+        (modules, classes, this env) out of the collector's reach; nothing else changes."""
         if engine is None:
             from .batch import RendezvousBatch
             p = params if params is not None else make_params(**env_kwargs)
@@ -88,9 +94,15 @@ class RendezvousVecEnv(_VecEnvBase):
             self.num_envs, self.observation_space, self.action_space = engine.num_envs, obs_space, act_space
         self.metadata = {"render.modes": []}
         self._actions = None
+        self._pack = None
+        self.copy_outputs = bool(copy_outputs)
         self._infos = [{} for _ in range(self.num_envs)]
         self._dirty = []
         self._t_start = time.time()
+        if gc_freeze:
+            import gc
+            gc.collect()
+            gc.freeze()
 
     # ------------------------------------------------------------------------------------------------ VecEnv API
     def reset(self):
@@ -103,35 +115,57 @@ class RendezvousVecEnv(_VecEnvBase):
         # pinned host memory run at ~150 MB/s on this platform: 10 ms for 65,536 x 6 floats)
         self._actions = torch.from_numpy(np.ascontiguousarray(a)).to(self.batch.device)
 
+    def _host_buffers(self):
+        """One packed device buffer [obs N x 17 | reward N | code N] and ONE reused (pageable) host array it is copied into per
+        step: a fresh `.cpu()` result per array costs an allocation and ~2,500 first-touch page faults per step at 65,536 envs."""
+        if self._pack is None:
+            n, dev = self.num_envs, self.batch.device
+            self._pack = torch.empty(n * 19, dtype=torch.float32, device=dev)
+            self._pack_obs = self._pack[: n * 17].view(n, 17)
+            self._pack_rew = self._pack[n * 17: n * 18]
+            self._pack_code = self._pack[n * 18:]
+            self._host = torch.empty(n * 19, dtype=torch.float32)
+            h = self._host.numpy()
+            self._h_obs, self._h_rew, self._h_code = h[: n * 17].reshape(n, 17), h[n * 17: n * 18], h[n * 18:]
+            self._fin_host = torch.empty((n, 19), dtype=torch.float32)          # rows of finished envs: terminal obs | return | length
+
     def step_wait(self):
         b = self.batch
-        obs, rew, done = b.step(self._actions)
-        # (measured and dropped: pinned staging buffers with non-blocking copies and one synchronisation — 2x slower here than
-        # three plain .cpu() calls)
-        obs_h, rew_h = obs.cpu().numpy(), rew.cpu().numpy()
-        done_h = done.cpu().numpy().astype(bool)
+        b.step(self._actions)
+        self._host_buffers()
+        # obs | reward | done_reason (0 = not done; bits as in RdvStepOut) leave the device as ONE message ...
+        self._pack_obs.copy_(b.obs); self._pack_rew.copy_(b.reward); self._pack_code.copy_(b.done_reason)
+        self._host.copy_(self._pack)                                             # (synchronises)
+        codes_f = self._h_code
+        done_h = codes_f != 0.0
+        if self.copy_outputs:
+            obs_h, rew_h = self._h_obs.copy(), self._h_rew.copy()
+        else:
+            obs_h, rew_h = self._h_obs, self._h_rew
         infos = self._infos
         for i in self._dirty:           # only the entries written last step are touched: O(#done), not O(N)
             infos[i] = {}
         self._dirty = []
         idx = np.flatnonzero(done_h)
         if idx.size:
-            # the rows of the finished envs are gathered on the device and cross PCIe once; the dicts are built from Python
-            # lists (tolist) rather than NumPy scalars: this loop is the cost of the SB3 boundary at 65,536 envs
+            # ... and the rows of the finished envs (terminal observation, episode return, length) as a second, small one: gathered on
+            # the device, ~5 % of the envs per step with random actions.  The dicts are built from Python lists (tolist), not NumPy
+            # scalars: this loop is the floor of the SB3 boundary (~0.45 us per finished env).
             sel = torch.from_numpy(idx).to(b.device)
-            packed = torch.cat([b.terminal_obs.index_select(0, sel),
-                                b.episode_return.index_select(0, sel).unsqueeze(1),
-                                b.episode_length.index_select(0, sel).to(torch.float32).unsqueeze(1),
-                                b.done_reason.index_select(0, sel).to(torch.float32).unsqueeze(1)], dim=1).cpu().numpy()
-            t_obs = np.ascontiguousarray(packed[:, :17])
+            k = idx.size
+            fin = self._fin_host[:k]
+            fin.copy_(torch.cat([b.terminal_obs.index_select(0, sel), b.episode_return.index_select(0, sel).unsqueeze(1),
+                                 b.episode_length.index_select(0, sel).to(torch.float32).unsqueeze(1)], dim=1))
+            packed = fin.numpy()
+            t_obs = packed[:, :17].copy()
             ep_r, ep_l = packed[:, 17].tolist(), packed[:, 18].astype(np.int64).tolist()
-            codes = packed[:, 19].astype(np.int64).tolist()
+            codes = codes_f[idx].astype(np.int64).tolist()
             now = round(time.time() - self._t_start, 6)
             idx_list = idx.tolist()
-            reasons = [_END_REASONS[c & 7] for c in codes]
-            for i, row, r, l, why, c in zip(idx_list, t_obs, ep_r, ep_l, reasons, codes):
+            reasons = _END_REASONS
+            for i, row, r, l, c in zip(idx_list, t_obs, ep_r, ep_l, codes):
                 infos[i] = {"terminal_observation": row, "episode": {"r": r, "l": l, "t": now},      # SB3 Monitor
-                            "end_reason": why, "collided": (c & 16) != 0, "success": (c & 32) != 0}
+                            "end_reason": reasons[c & 7], "collided": (c & 16) != 0, "success": (c & 32) != 0}
             if not self.quiet:                                                           # :376-382
                 for j in range(len(idx_list)):
                     code = codes[j]

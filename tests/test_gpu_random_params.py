@@ -184,3 +184,21 @@ def test_adversarial_states_match_the_reference_golden():
         env.close()
         return out
     check_adversarial(step_fn, nan_pattern=False)
+
+
+def test_threshold_boundaries_on_the_gpu():
+    """boundary_diag.npz through the HIP path (fp64 storage): error norms that equal a limit or sit 1-2 ulp either side of it must
+    fall on the reference's side of `<=` (check_success, :416) and `<` (check_collision, :397).  The kernel compares sums of squares
+    with host-derived thresholds (largest double whose correctly rounded sqrt still satisfies the comparison): exact, no sqrt."""
+    from test_oracle_golden import check_boundaries
+    from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+
+    def diagnose_fn(states):
+        env = RendezvousBatch(len(states), device="cuda:0", storage="f64", on_done="halt")
+        env.reset()
+        env.set_state(torch.from_numpy(states))
+        d = env.diagnose().cpu().numpy()
+        # the same decisions inside a step: zero action, check the latched / counted flags one step later against the oracle
+        env.close()
+        return d
+    check_boundaries(diagnose_fn)

@@ -174,12 +174,24 @@ def _worker(rank, world, port, n_global, steps, q):
         n, p, storage="f32", seed=21, env_id_offset=env_id_offset))
     obs = env.reset()
     trace = []
+    rg = sharding.RolloutGather(hi - lo, torch.device("cpu"))              # one packed [n,19] message per rank and step, buffers reused
     for t in range(steps):
         a = torch.from_numpy(counter_actions(3, t, n_global)[lo:hi])        # actions keyed by GLOBAL env id
         obs, rew, done = env.step(a)
-        g = sharding.gather_rollout([obs, rew, done.to(torch.uint8)])
+        if t % 2:
+            g = rg.gather(obs, rew, done.to(torch.uint8))
+            g = None if g is None else [g[0], g[1], g[2].to(torch.uint8)]
+        else:
+            g = sharding.gather_rollout([obs, rew, done.to(torch.uint8)])
         if rank == 0:
+            assert g[0].shape == (n_global, 17) and g[0].is_contiguous() is False and g[0].untyped_storage().data_ptr() == g[1].untyped_storage().data_ptr()
             trace.append([x.numpy().copy() for x in g])
+    try:                                                                     # shards of different sizes cannot be gathered: refused, not hung
+        sharding.RolloutGather(hi - lo + rank, torch.device("cpu"))
+        unequal_refused = False
+    except ValueError:
+        unequal_refused = True
+    assert unequal_refused
     total = sharding.reduce_stats(env.get_stats())
     cols = sharding.gather_columns({"lo": np.full(hi - lo, lo), "ret": env.get_aux()[:, 6].numpy()})
     if rank == 0:

@@ -13,11 +13,24 @@ acts = [rng.uniform(-1, 1, (n, 6)).astype(np.float32) for _ in range(8)]
 vec.reset()
 for k in range(30):
     vec.step(acts[k % 8])
-t0 = time.perf_counter()
-for k in range(20):
+import gc
+per = []
+for k in range(60):
+    t0 = time.perf_counter()
     vec.step(acts[k % 8])
-dt = (time.perf_counter() - t0) / 20
-print(f"{dt * 1e3:.2f} ms per step, {n / dt * 1e-6:.2f} M env steps/s")
+    per.append(time.perf_counter() - t0)
+per_ms = np.array(per) * 1e3
+dt = per_ms.mean() * 1e-3
+print(f"{dt * 1e3:.2f} ms per step (median {np.median(per_ms):.2f}, min {per_ms.min():.2f}, max {per_ms.max():.2f}), {n / dt * 1e-6:.2f} M env steps/s; gc counts {gc.get_count()}, thresholds {gc.get_threshold()}")
+print("per-step ms:", " ".join(f"{x:.1f}" for x in per_ms[:40]))
+gc.disable()
+per = []
+for k in range(40):
+    t0 = time.perf_counter()
+    vec.step(acts[k % 8])
+    per.append(time.perf_counter() - t0)
+print(f"with the garbage collector off: {np.mean(per) * 1e3:.2f} ms per step (median {np.median(per) * 1e3:.2f})")
+gc.enable()
 pr = cProfile.Profile()
 pr.enable()
 for k in range(20):
