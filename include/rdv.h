@@ -34,6 +34,7 @@ extern "C" {
 #define RDV_ACT_DIM 6     /* rendezvous_env.py:140-144 */
 #define RDV_STATE_DIM 20  /* rc3 vc3 qc4 wc3 qt4 wt3, the column order of results/data_monte_carlo_initial_conditions.csv */
 #define RDV_DIAG_DIM 8    /* pos_err, vel_err, att_err, rot_err, in_koz(now), success(now), dist_from_koz, collided(latched) */
+#define RDV_EVAL_DIM 32   /* per-env evaluation accumulators, see rdv_eval_begin */
 
 typedef enum RdvError {
   RDV_OK = 0,
@@ -125,6 +126,7 @@ typedef struct RdvStepOut {
   uint8_t* done_reason;     /* [N]    nullable; bits 0-2: 0 = not done, 1 obs, 2 time, 3 bubble, 4 attitude (rendezvous_env.py:377);
                                       where done also bit 4 = the episode entered the keep-out zone, bit 5 = it had >= 1 success step */
   double*  diag;            /* [N,8]  nullable; evaluator diagnostics of the post-step (pre-reset) state, RDV_DIAG_DIM */
+  double*  eval;            /* [N,32] nullable; per-env evaluation accumulators (rdv_eval_begin), updated where the env stepped */
 } RdvStepOut;
 
 /* Episode statistics accumulated on device (the list logged by custom/custom_callbacks.py:285-298): per step one
@@ -245,6 +247,30 @@ int rdv_restore(rdv_handle h, const void* src, int64_t src_bytes, void* stream);
 /* get_observation() (:294) and the evaluator helpers (:388-468, :510) on the current state. */
 int rdv_observe(rdv_handle h, float* obs_out, void* stream);
 int rdv_diagnose(rdv_handle h, double* diag_out, void* stream);
+
+/*
+ * Episode-level evaluation on the device: what the reference's evaluators collect on the host after every step —
+ * CustomWandbCallback.evaluate_policy (custom/custom_callbacks.py:211-267: sum of attitude errors, steps inside the keep-out zone,
+ * time of the first one, smallest position error before it, total reward) and monte_carlo.evaluate (monte_carlo.py:117-205: collision
+ * and success step counts, minimum distance from the KOZ, and the terminal errors of :153-189 as running sums per constraint level,
+ * so that no error history is kept) — accumulated per env by rdv_step (halt mode) into `eval` [N, RDV_EVAL_DIM] fp64:
+ *   0 total reward | 1 steps | 2 sum of attitude errors (k = 0 included) | 3 steps inside the KOZ | 4 time of the first one (NaN: none)
+ *   5 smallest position error before it (NaN: none) | 6 success steps | 7 min dist_from_koz | 8-11 last errors (pos, vel, att, rot)
+ *   then four blocks {count, sum pos, sum vel, sum att, sum rot} of the steps from the first one at which the errors met
+ *   12: all four limits (:163) | 17: pos, vel and (att or rot) (:167) | 22: pos and vel (:172) | 27: pos (:175)   (strict `<`)
+ * rdv_eval_begin writes the k = 0 entries from the current state (after rdv_reset / rdv_set_state, as the evaluators do);
+ * rdv_eval_summary reduces the batch to the twelve means the callback logs (:285-298) with one wavefront reduction per 64 envs
+ * (synchronises `stream`).
+ */
+typedef struct RdvEvalSummary {
+  double ep_rew, ep_len, ep_dist, ep_delta_v, ep_delta_w, ep_success, ep_collision_percentage;
+  double ep_time_of_first_collision;   /* mean over the episodes that had one; -1 if none had (:274-277) */
+  double ep_min_pos_error;             /* likewise (:279-282) */
+  double ep_avg_att_error, pct_collided_episodes, pct_successful_episodes;
+  int64_t episodes;
+} RdvEvalSummary;
+int rdv_eval_begin(rdv_handle h, double* eval, void* stream);
+int rdv_eval_summary(rdv_handle h, const double* eval, RdvEvalSummary* out_host, void* stream);
 
 /* Copy the device statistics to the host (synchronises `stream`); reset != 0 zeroes them afterwards. */
 int rdv_get_stats(rdv_handle h, RdvStats* out_host, int reset, void* stream);

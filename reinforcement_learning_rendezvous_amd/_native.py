@@ -16,7 +16,7 @@ CSRC = os.path.join(_PKG, "csrc")
 STORAGE_F32, STORAGE_F64 = 0, 1
 ON_DONE_RESET, ON_DONE_HALT, ON_DONE_CONTINUE = 0, 1, 2
 VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT = 0, 1, 2
-OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM = 17, 6, 20, 8, 8
+OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM, EVAL_DIM = 17, 6, 20, 8, 8, 32
 
 ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVICE", -3: "RDV_ERR_HIP",
                -4: "RDV_ERR_OUT_OF_MEMORY", -5: "RDV_ERR_BAD_HANDLE", -6: "RDV_ERR_BAD_PARAMS"}
@@ -26,7 +26,7 @@ SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_va
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
            "rdv_set_kernel_variant", "rdv_rigid_body_default", "rdv_set_rigid_body", "rdv_get_rigid_body",
            "rdv_reset", "rdv_step", "rdv_step_many", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_snapshot_bytes", "rdv_snapshot", "rdv_restore", "rdv_observe", "rdv_diagnose",
-           "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act", "rdv_critic_create", "rdv_policy_value", "rdv_rollout"]
+           "rdv_eval_begin", "rdv_eval_summary", "rdv_get_stats", "rdv_num_envs", "rdv_policy_create", "rdv_policy_destroy", "rdv_policy_act", "rdv_critic_create", "rdv_policy_value", "rdv_rollout"]
 
 
 class RdvError(RuntimeError):
@@ -39,7 +39,7 @@ class StepOut(C.Structure):
     """RdvStepOut"""
     _fields_ = [("obs", C.c_void_p), ("reward", C.c_void_p), ("done", C.c_void_p), ("terminal_obs", C.c_void_p),
                 ("episode_return", C.c_void_p), ("episode_length", C.c_void_p), ("done_reason", C.c_void_p),
-                ("diag", C.c_void_p)]
+                ("diag", C.c_void_p), ("eval", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -53,6 +53,13 @@ class Stats(C.Structure):
                     collisions=int(self.collisions), reasons=[int(x) for x in self.reasons],
                     sum_return=float(self.sum_return), sum_length=float(self.sum_length),
                     sum_delta_v=float(self.sum_delta_v), sum_delta_w=float(self.sum_delta_w))
+
+
+class EvalSummary(C.Structure):
+    """RdvEvalSummary: the twelve means custom_callbacks.evaluate_policy logs (:285-298)"""
+    _fields_ = [(k, C.c_double) for k in ("ep_rew", "ep_len", "ep_dist", "ep_delta_v", "ep_delta_w", "ep_success", "ep_collision_percentage",
+                                           "ep_time_of_first_collision", "ep_min_pos_error", "ep_avg_att_error", "pct_collided_episodes",
+                                           "pct_successful_episodes")] + [("episodes", C.c_int64)]
 
 
 class RolloutOut(C.Structure):
@@ -121,6 +128,8 @@ def lib():
         "rdv_restore": (C.c_int, [vp, vp, i64, vp]),
         "rdv_observe": (C.c_int, [vp, vp, vp]),
         "rdv_diagnose": (C.c_int, [vp, vp, vp]),
+        "rdv_eval_begin": (C.c_int, [vp, vp, vp]),
+        "rdv_eval_summary": (C.c_int, [vp, vp, C.POINTER(EvalSummary), vp]),
         "rdv_get_stats": (C.c_int, [vp, C.POINTER(Stats), C.c_int, vp]),
         "rdv_num_envs": (i64, [vp]),
         "rdv_policy_create": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.POINTER(vp)]),

@@ -59,11 +59,12 @@ class RendezvousBatch:
         self.episode_length = torch.zeros(n, dtype=torch.int32, device=dev)
         self.done_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
         self.diag = None
+        self.eval = None
         self._tape = None
         self._out = N.StepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
                               self.terminal_obs.data_ptr(), self.episode_return.data_ptr(),
-                              self.episode_length.data_ptr(), self.done_reason.data_ptr(), None)
-        self._out_diag = None
+                              self.episode_length.data_ptr(), self.done_reason.data_ptr(), None, None)
+        self._outs = {}
 
     # ------------------------------------------------------------------------------------------------ plumbing
     def _stream(self):
@@ -101,21 +102,47 @@ class RendezvousBatch:
             N.check(self._lib.rdv_observe(self._h, self.obs.data_ptr(), self._stream()))
         return self.obs
 
-    def step(self, actions, diag=False):
+    def step(self, actions, diag=False, accumulate=False):
         """RendezvousEnv.step() (rendezvous_env.py:160-221) for every env: one kernel launch.
 
         Returns (obs, reward, done): views of buffers that the next step overwrites.  ``terminal_obs``,
-        ``episode_return``, ``episode_length`` (valid where done) and ``done_reason`` are attributes."""
+        ``episode_return``, ``episode_length`` (valid where done) and ``done_reason`` are attributes.
+        ``diag``: also write the evaluator diagnostics of the post-step state to ``self.diag`` [N,8].
+        ``accumulate``: also update the per-env evaluation accumulators ``self.eval`` [N,32] (``eval_begin`` first)."""
         self._check_tensor(actions, (self.num_envs, N.ACT_DIM), torch.float32, "actions")
-        out = self._out
-        if diag:
-            if self.diag is None:
+        key = (bool(diag), bool(accumulate))
+        out = self._outs.get(key)
+        if out is None:
+            if diag and self.diag is None:
                 self.diag = torch.zeros((self.num_envs, N.DIAG_DIM), dtype=torch.float64, device=self.device)
-                self._out_diag = N.StepOut(*[getattr(self._out, f) for f, _ in N.StepOut._fields_[:-1]],
-                                           self.diag.data_ptr())
-            out = self._out_diag
+            if accumulate and self.eval is None:
+                raise N.RdvError(-1, "step(accumulate=True): call eval_begin() first")
+            base = [getattr(self._out, f) for f, _ in N.StepOut._fields_[:-2]]
+            out = N.StepOut(*base, self.diag.data_ptr() if diag else None, self.eval.data_ptr() if accumulate else None)
+            self._outs[key] = out
         N.check(self._lib.rdv_step(self._h, actions.data_ptr(), C.byref(out), self._stream()))
         return self.obs, self.reward, self.done
+
+    # ------------------------------------------------------------------------------------------------ evaluation on the device
+    def eval_begin(self):
+        """Start the per-env evaluation accumulators from the current state (after ``reset`` / ``set_state``): ``self.eval`` [N,32]
+        float64 on the device then follows every ``step(..., accumulate=True)`` — what the reference's evaluators collect on the
+        host after each step (custom_callbacks.py:211-267, monte_carlo.py:117-205; layout in include/rdv.h, rdv_eval_begin)."""
+        if self.eval is None:
+            self.eval = torch.zeros((self.num_envs, N.EVAL_DIM), dtype=torch.float64, device=self.device)
+            self._outs = {k: v for k, v in self._outs.items() if not k[1]}
+        N.check(self._lib.rdv_eval_begin(self._h, self.eval.data_ptr(), self._stream()))
+        return self.eval
+
+    def eval_summary(self):
+        """The twelve means ``CustomWandbCallback.evaluate_policy`` logs (custom_callbacks.py:285-298) over the batch's envs, reduced
+        on the device (one wavefront reduction per 64 envs)."""
+        st = N.EvalSummary()
+        N.check(self._lib.rdv_eval_summary(self._h, self.eval.data_ptr(), C.byref(st), self._stream()))
+        d = {k: float(getattr(st, k)) for k, _ in N.EvalSummary._fields_[:-1]}
+        d["%_collided_episodes"] = d.pop("pct_collided_episodes")
+        d["%_successfull_episodes"] = d.pop("pct_successful_episodes")
+        return d
 
     def step_many(self, actions, out=None):
         """``step`` for every row of an OPEN-LOOP action tape ``actions`` [K,N,6] in ONE kernel launch (state in registers, no
@@ -129,7 +156,7 @@ class RendezvousBatch:
                        done=torch.empty((K, n), dtype=torch.uint8, device=dev),
                        done_reason=torch.empty((K, n), dtype=torch.uint8, device=dev))
         so = N.StepOut(out["obs"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(), None, None, None,
-                       out["done_reason"].data_ptr(), None)
+                       out["done_reason"].data_ptr(), None, None)
         N.check(self._lib.rdv_step_many(self._h, actions.data_ptr(), K, C.byref(so), self._stream()))
         self.obs.copy_(out["obs"][K - 1]); self.reward.copy_(out["reward"][K - 1]); self.done.copy_(out["done"][K - 1])
         return out

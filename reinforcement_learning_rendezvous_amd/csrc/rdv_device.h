@@ -53,7 +53,7 @@ struct DevParams {
   // sum of squares s (formed as the reference's NumPy forms it: sumsq3) and compares it with
   // the largest double T for which sqrt(T) <= limit (le2_*) or sqrt(T) < limit (lt2_*), found on the host with the correctly rounded
   // sqrt: since sqrt is monotone, s <= T decides exactly what sqrt(s) <= limit decides — no sqrt, and no off-by-an-ulp of limit^2.
-  double le2_rd, lt2_rd, le2_vd, le2_wd, lt2_koz;
+  double le2_rd, lt2_rd, le2_vd, lt2_vd, le2_wd, lt2_wd, lt2_koz;
   // thresholds on k = rint(1e5*cos) equivalent to the reference's tests on acos(round(cos,5)) (general.py:179)
   double reset_flag_radius2;            // (max(koz_radius, |rd| + max_rd_error))^2: beyond it a fresh state has collided = success = 0
   double kc_coll_max;                   // in corridor cone test (:401): angle > half_angle      <=> k <= kc_coll_max
@@ -648,6 +648,7 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Env& e, uint64_t s
 struct StepResult {
   float obs[17];
   float reward;
+  double reward64;   // the reward before its float32 store (the reference's evaluators sum the float64 value, monte_carlo.py:150)
   int done;      // 0/1
   int reason;    // 0 none, 1 obs, 2 time, 3 bubble, 4 attitude
 };
@@ -734,6 +735,7 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   }
   e.ep_ret = canon(e.ep_ret + rew, tag);
   r.reward = (float)rew;
+  r.reward64 = rew;
 }
 
 // diagnostics row (RDV_DIAG_DIM = 8) — evaluator-only
@@ -743,6 +745,53 @@ __device__ __forceinline__ void diagnostics(const DevParams& P, const Env& e, co
   out[5] = (!(e.flags & FLAG_COLLIDED) && errors_ok(P, d)) ? 1.0 : 0.0;    // check_success (:406-422)
   out[6] = dist_from_koz(P, d);
   out[7] = (e.flags & FLAG_COLLIDED) ? 1.0 : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-env evaluation accumulators (RDV_EVAL_DIM = 32 doubles per env), updated by the evaluator build of the step kernel where an
+// env executed a transition: everything the reference's evaluators gather step by step on the host, kept on the device —
+//   custom_callbacks.evaluate_policy (:211-267): sum of attitude errors, steps inside the keep-out zone, time of the first one,
+//     smallest position error before it, total reward;
+//   monte_carlo.evaluate (:117-205): number of collision / success steps, minimum distance from the KOZ, and the terminal errors:
+//     the mean of each error from the first step at which all four (else three, else two, else one) constraints hold (:153-189) —
+//     kept as running sums per level, which needs no error history: a level's sum starts at its first hit and runs to the end.
+// Layout: 0 total reward, 1 steps, 2 sum att, 3 collision steps, 4 t of first collision (NaN: none), 5 min pos error before it (NaN: none),
+// 6 success steps, 7 min dist from KOZ, 8-11 last errors, then four levels {count, sum pos, vel, att, rot}: 12 all four, 17 three, 22 two, 27 one.
+constexpr int kEvalDim = 32;
+// dg: the diagnostics row of the state the accumulators are updated with; first = true for the initial state (k = 0)
+__device__ __forceinline__ void eval_accumulate(const DevParams& P, const Env& e, const Derived& d, const double* dg, double reward,
+                                                bool first, double* acc) {
+  const bool koz = dg[4] != 0.0;
+  const double t_now = rint((double)e.k * P.dt * 1e3) / 1e3;                     // :193
+  if (first) {
+    acc[0] = 0.0; acc[1] = 0.0; acc[2] = dg[2];                                   // :213
+    acc[3] = koz ? 1.0 : 0.0;                                                     // :215-220
+    acc[4] = koz ? 0.0 : __builtin_nan("");
+    acc[5] = koz ? __builtin_nan("") : dg[0];                                     // :221-222
+    acc[6] = dg[5]; acc[7] = dg[6];                                               // monte_carlo.py:121-123
+  } else {
+    acc[0] += reward; acc[1] += 1.0; acc[2] += dg[2];                             // :242-243
+    const bool no_coll_yet = acc[4] != acc[4];
+    if (koz) { acc[3] += 1.0; if (no_coll_yet) acc[4] = t_now; }                  // :244-248
+    else if (no_coll_yet) acc[5] = fmin(acc[5], dg[0]);                           // :249-252
+    acc[6] += dg[5];                                                              // monte_carlo.py:145-146
+    acc[7] = fmin(acc[7], dg[6]);                                                 // monte_carlo.py:147-149
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[8 + j] = dg[j];
+  // monte_carlo.py:159-162: strict comparisons of the four errors with their limits
+  const bool p = d.pos2 <= P.lt2_rd, v = d.vel2 <= P.lt2_vd, a = d.k_att >= P.ka_bonus_min, r = d.rot2 <= P.lt2_wd;
+  const bool hit[4] = {p && v && a && r, (p && v && a) || (p && v && r), p && v, p};      // :163, :167, :172, :175
+#pragma unroll
+  for (int L = 0; L < 4; ++L) {
+    double* lv = acc + 12 + 5 * L;
+    if (first) { lv[0] = 0.0; lv[1] = lv[2] = lv[3] = lv[4] = 0.0; }
+    if (lv[0] > 0.0 || hit[L]) {
+      lv[0] += 1.0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lv[1 + j] += dg[j];
+    }
+  }
 }
 
 }  // namespace rdv

@@ -119,6 +119,7 @@ struct StepArgs {
   int32_t* episode_length;  // nullable
   uint8_t* done_reason;     // nullable
   double* diag;             // nullable [N,8]
+  double* eval;             // nullable [N,32]: per-env evaluation accumulators (eval_accumulate)
   const double* tape;       // nullable [depth][N][20]
   int64_t n;
   uint64_t seed;
@@ -287,7 +288,7 @@ __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i,
 template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false>
 __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, int64_t i, bool active, Env& e, const float* a,
                                         StepResult& r) {
-  r.done = 0; r.reason = 0; r.reward = 0.0f;
+  r.done = 0; r.reason = 0; r.reward = 0.0f; r.reward64 = 0.0;
 #pragma unroll
   for (int j = 0; j < RDV_OBS_DIM; ++j) r.obs[j] = 0.0f;
   bool stepped = false;
@@ -296,11 +297,19 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
     if (e.flags & FLAG_HALTED) {
       observation(P, e, r.obs);
       r.done = 1;
-      if (kDiag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
+      if (kDiag && A.diag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
     } else {
       step_env<ST, !kDiag, kGeneral, kRaw>(P, e, a, r, d);
       stepped = true;
-      if (kDiag) diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM);   // evaluator build only: keeps the training kernel short
+      if (kDiag) {   // evaluator build only: keeps the training kernel short
+        double dg[RDV_DIAG_DIM];
+        diagnostics(P, e, d, dg);
+        if (A.diag) {
+#pragma unroll
+          for (int j = 0; j < RDV_DIAG_DIM; ++j) A.diag[i * RDV_DIAG_DIM + j] = dg[j];
+        }
+        if (A.eval) eval_accumulate(P, e, d, dg, r.reward64, false, A.eval + i * kEvalDim);
+      }
     }
   }
   return stepped;
@@ -538,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams* __restri
   refill_whole<ST>(A, P, i, counter + 1u);
 }
 
-enum { ACC_SET_STATE = 0, ACC_GET_STATE, ACC_GET_AUX, ACC_OBSERVE, ACC_DIAGNOSE };
+enum { ACC_SET_STATE = 0, ACC_GET_STATE, ACC_GET_AUX, ACC_OBSERVE, ACC_DIAGNOSE, ACC_EVAL_BEGIN };
 
 // state access / evaluator helpers (cold paths; one lane per env, row-major host-facing arrays)
 template <typename ST>
@@ -568,10 +577,52 @@ __global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void*
     float o[RDV_OBS_DIM];
     observation(P, e, o);
     for (int j = 0; j < RDV_OBS_DIM; ++j) out_f32[i * RDV_OBS_DIM + j] = o[j];
-  } else {
+  } else if (what == ACC_DIAGNOSE) {
     Derived d;
     derive<false>(P, e, d);
     diagnostics(P, e, d, out + i * RDV_DIAG_DIM);
+  } else {            // ACC_EVAL_BEGIN: the accumulators' k = 0 entries, from the state as it stands (after reset / set_state)
+    Derived d;
+    derive<false>(P, e, d);
+    double dg[RDV_DIAG_DIM];
+    diagnostics(P, e, d, dg);
+    eval_accumulate(P, e, d, dg, 0.0, true, out + i * kEvalDim);
+  }
+}
+
+// The means CustomWandbCallback.evaluate_policy logs (custom_callbacks.py:254-298) over the batch's envs, from the evaluation
+// accumulators and the final state: one wavefront reduction (DPP sums, fixed order) per 64 envs into that wave's 16-double slot; the
+// host adds the slots in index order.
+enum { EV_REW = 0, EV_LEN, EV_DIST, EV_DV, EV_DW, EV_SUCC, EV_COLLP, EV_TFIRST, EV_TFIRST_N, EV_MINPOS, EV_MINPOS_N, EV_AVGATT, EV_NCOLL, EV_NSUCC, EV_N, EV_SLOTS = 16 };
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void eval_summary_kernel(const DevParams P, const void* ws_, int64_t n, const double* eval, double* partial) {
+  using V = typename Vec4<ST>::type;
+  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & (kWave - 1);
+  double v[EV_N + 1];
+#pragma unroll
+  for (int j = 0; j <= EV_N; ++j) v[j] = 0.0;
+  if (i < n) {
+    Env e;
+    load_env<ST>(reinterpret_cast<const V*>(ws_), n, i, e);
+    const double* acc = eval + i * kEvalDim;
+    const double end_time = rint((double)e.k * P.dt * 1e3) / 1e3;      // :254
+    const double steps = end_time / P.dt;                              // :255
+    v[EV_REW] = acc[0]; v[EV_LEN] = end_time; v[EV_DIST] = sqrt(sumsq3(e.rc));                 // :258-260
+    v[EV_DV] = e.sum_dv; v[EV_DW] = e.sum_dw; v[EV_SUCC] = (double)(e.flags >> SUCCESS_SHIFT);  // :261-263
+    v[EV_COLLP] = acc[3] / steps * 100.0;                                                      // :264
+    const bool has_t = acc[4] == acc[4], has_p = acc[5] == acc[5];
+    v[EV_TFIRST] = has_t ? acc[4] : 0.0; v[EV_TFIRST_N] = has_t ? 1.0 : 0.0;                    // :265, nanmean :274-282
+    v[EV_MINPOS] = has_p ? acc[5] : 0.0; v[EV_MINPOS_N] = has_p ? 1.0 : 0.0;                    // :266
+    v[EV_AVGATT] = acc[2] / (steps + 1.0);                                                     // :267
+    v[EV_NCOLL] = acc[3] > 0.0 ? 1.0 : 0.0; v[EV_NSUCC] = (e.flags >> SUCCESS_SHIFT) != 0u ? 1.0 : 0.0;   // :268-269
+    v[EV_N] = 1.0;
+  }
+  double* slot = partial + (uint64_t)(i / kWave) * EV_SLOTS;
+#pragma unroll
+  for (int j = 0; j <= EV_N; ++j) {
+    const double s = wave_sum_f64(v[j]);
+    if (lane == 0 && (i - lane) < n) slot[j] = s;
   }
 }
 
@@ -600,11 +651,17 @@ static int fail(int code, const char* fmt, ...) {
   va_end(ap);
   return code;
 }
+// A failed HIP call also leaves its code in the runtime's per-thread "last error", which the NEXT caller of hipGetLastError() would
+// be handed — e.g. PyTorch's launch check after its next kernel, which would then raise for a failure that was ours and has been
+// reported through this ABI.  Reading it here clears it.
 #define RDV_HIP(call)                                                                                       \
   do {                                                                                                      \
     hipError_t err__ = (call);                                                                              \
-    if (err__ != hipSuccess) return fail(err__ == hipErrorOutOfMemory ? RDV_ERR_OUT_OF_MEMORY : RDV_ERR_HIP, \
-                                         "%s failed: %s", #call, hipGetErrorString(err__));                 \
+    if (err__ != hipSuccess) {                                                                              \
+      (void)hipGetLastError();                                                                              \
+      return fail(err__ == hipErrorOutOfMemory ? RDV_ERR_OUT_OF_MEMORY : RDV_ERR_HIP,                       \
+                  "%s failed: %s", #call, hipGetErrorString(err__));                                        \
+    }                                                                                                       \
   } while (0)
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
@@ -617,6 +674,7 @@ static inline int64_t acos_bytes() { return align_up((int64_t)kAcosEntries * (in
 // prepared next-episode states (rdv_slots.h): one record per env (7 chunks + 5 float4 of observation), one tag per env
 static inline int64_t prep_bytes(int64_t n, int storage) { return align_up(n * (storage == RDV_STORAGE_F64 ? slot_record_bytes<double>() : slot_record_bytes<float>()), 256); }
 static inline int64_t prep_tag_bytes(int64_t n) { return align_up(n * 4, 256); }
+static inline int64_t eval_partial_bytes(int64_t n) { return align_up(n_waves(n) * EV_SLOTS * (int64_t)sizeof(double), 256); }   // eval_summary_kernel
 
 // Largest integer k in [-100000, 100000] for which acos(k/1e5) > theta (strict) or >= theta; -100001 if there is none.
 // acos(k/1e5) is what general.py:179 evaluates for every cosine that rounds to k*1e-5, so comparing k with this
@@ -677,6 +735,7 @@ static void derive_params(const RdvParams& p, DevParams& d) {
   d.inv_corridor_norm = 1.0 / norm3h(p.corridor_axis); d.inv_capture_norm = 1.0 / norm3h(p.capture_axis);
   d.le2_rd = sq_threshold(p.max_rd_error, false); d.lt2_rd = sq_threshold(p.max_rd_error, true);        // :416 (<=), :348 (<)
   d.le2_vd = sq_threshold(p.max_vd_error, false); d.le2_wd = sq_threshold(p.max_wd_error, false);       // :416-417
+  d.lt2_vd = sq_threshold(p.max_vd_error, true); d.lt2_wd = sq_threshold(p.max_wd_error, true);         // monte_carlo.py:160, :162 (<)
   d.lt2_koz = sq_threshold(p.koz_radius, true);                                                        // :397, :340
   {  // an initial state can only be inside the KOZ sphere or meet the capture position error within this radius of the target
     const double rr = std::fmax(p.koz_radius, norm3h(p.rd) + p.max_rd_error) * (1.0 + 1e-9);
@@ -731,6 +790,8 @@ struct RdvEnvBatch {
   bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
   void* prep;        // prepared next-episode states (rdv_slots.h): records, tags
   uint32_t* prep_tag;
+  double* eval_partial;   // per-wave partial sums of rdv_eval_summary
+  std::vector<double> host_eval;
   bool prepared_ok;  // every slot holds what the env's next reset returns (false: prepare_kernel runs before the next slot-using launch)
 #ifdef RDV_STAMPS
   unsigned long long* stamps = nullptr;
@@ -816,7 +877,7 @@ int rdv_params_validate(const RdvParams* p) {
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
   if (n_envs <= 0 || (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64)) return -1;
   return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes() + acos_bytes() +
-         prep_bytes(n_envs, storage) + prep_tag_bytes(n_envs);
+         prep_bytes(n_envs, storage) + prep_tag_bytes(n_envs) + eval_partial_bytes(n_envs);
 }
 
 int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
@@ -893,7 +954,7 @@ static int create_mlp(const float* w1, const float* b1, const float* w2, const f
   // the kernels keep the parameter block and the staged rows in 72 KiB of dynamic LDS (above the 64 KiB default limit)
   if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(policy_act_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPolLdsBytes);
   if (err == hipSuccess) err = hipFuncSetAttribute(reinterpret_cast<const void*>(policy_value_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kPolLdsBytes);
-  if (err != hipSuccess) { if (p->weights) (void)hipFree(p->weights); delete p; return fail(RDV_ERR_HIP, "rdv_policy_create: %s", hipGetErrorString(err)); }
+  if (err != hipSuccess) { (void)hipGetLastError(); if (p->weights) (void)hipFree(p->weights); delete p; return fail(RDV_ERR_HIP, "rdv_policy_create: %s", hipGetErrorString(err)); }
   *out = p;
   return RDV_OK;
 }
@@ -999,7 +1060,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   if (workspace) { h->ws = workspace; h->own_ws = false; }
   else {
     hipError_t err = hipMalloc(&h->ws, (size_t)bytes);
-    if (err != hipSuccess) { delete h; return fail(RDV_ERR_OUT_OF_MEMORY, "hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(err)); }
+    if (err != hipSuccess) { (void)hipGetLastError(); delete h; return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_create: hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(err)); }
     h->own_ws = true;
   }
   h->stats = reinterpret_cast<uint64_t*>(static_cast<char*>(h->ws) + chunk_bytes(n_envs, storage));
@@ -1007,6 +1068,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->acos_table = reinterpret_cast<double*>(reinterpret_cast<char*>(h->dev_params) + params_bytes());
   h->prep = reinterpret_cast<char*>(h->acos_table) + acos_bytes();
   h->prep_tag = reinterpret_cast<uint32_t*>(static_cast<char*>(h->prep) + prep_bytes(n_envs, storage));
+  h->eval_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(h->prep_tag) + prep_tag_bytes(n_envs));
   h->prepared_ok = false;
   h->dev.acos_table = h->acos_table;
   // every step of the set-up reports itself: which call failed, and why
@@ -1025,6 +1087,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   if (err == hipSuccess) { what = "hipFuncSetAttribute(step_many_kernel<float>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<float>()); }
   if (err == hipSuccess) { what = "hipFuncSetAttribute(step_many_kernel<double>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<double>()); }
   if (err != hipSuccess) {
+    (void)hipGetLastError();
     if (h->own_ws) (void)hipFree(h->ws);
     delete h;
     return fail(err == hipErrorOutOfMemory ? RDV_ERR_OUT_OF_MEMORY : RDV_ERR_HIP, "rdv_create: %s failed: %s", what, hipGetErrorString(err));
@@ -1196,7 +1259,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   A.actions = actions;
   A.obs = out->obs; A.reward = out->reward; A.done = out->done; A.terminal_obs = out->terminal_obs;
   A.episode_return = out->episode_return; A.episode_length = out->episode_length; A.done_reason = out->done_reason;
-  A.diag = out->diag;
+  A.diag = out->diag; A.eval = out->eval;
+  if (A.eval && (reinterpret_cast<uintptr_t>(A.eval) & 7)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: eval must be 8-byte aligned");
 #ifdef RDV_STAMPS
   A.stamps = h->stamps;
 #endif
@@ -1205,9 +1269,9 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   // the evaluator-diagnostics build and the first step after rdv_set_state (kRaw)
   const bool raw = h->raw_state && !h->general;   // (the RK45 kernels integrate the quaternion as given, like the reference)
   h->raw_state = false;
-  const bool split = !A.diag && !h->general && !raw && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
+  const bool split = !A.diag && !A.eval && !h->general && !raw && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
 #define RDV_LAUNCH(KERNEL, GRID, BLOCK) hipLaunchKernelGGL((KERNEL), GRID, BLOCK, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A)
-  const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr;
+  const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr || A.eval != nullptr;   // either one: the evaluator build
   if (split) {
     const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
     if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
@@ -1235,8 +1299,8 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if (n_steps <= 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: n_steps must be positive (got %d)", n_steps);
   if (!actions || !out || !out->obs || !out->reward || !out->done)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions, obs, reward and done are required");
-  if (out->terminal_obs || out->episode_return || out->episode_length || out->diag)
-    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: terminal_obs, episode_return, episode_length and diag are outputs of rdv_step only");
+  if (out->terminal_obs || out->episode_return || out->episode_length || out->diag || out->eval)
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: terminal_obs, episode_return, episode_length, diag and eval are outputs of rdv_step only");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: call rdv_reset first (state is undefined until reset(), as in the reference)");
   if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_step");
   if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
@@ -1348,6 +1412,39 @@ int rdv_diagnose(rdv_handle h, double* out, void* stream) {
   RDV_CHECK_HANDLE(h);
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_diagnose: null output");
   return access(h, ACC_DIAGNOSE, nullptr, out, nullptr, stream);
+}
+
+int rdv_eval_begin(rdv_handle h, double* eval, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!eval) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_eval_begin: null accumulators");
+  if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_eval_begin: call rdv_reset first");
+  return access(h, ACC_EVAL_BEGIN, nullptr, eval, nullptr, stream);
+}
+int rdv_eval_summary(rdv_handle h, const double* eval, RdvEvalSummary* out, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  if (!eval || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_eval_summary: null accumulators / output");
+  DeviceGuard guard(h->device);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(eval_summary_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, eval, h->eval_partial);
+  else hipLaunchKernelGGL(eval_summary_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, eval, h->eval_partial);
+  RDV_HIP(hipGetLastError());
+  const size_t waves = (size_t)((h->n + kWave - 1) / kWave);
+  h->host_eval.resize(waves * EV_SLOTS);
+  RDV_HIP(hipMemcpyAsync(h->host_eval.data(), h->eval_partial, waves * EV_SLOTS * sizeof(double), hipMemcpyDeviceToHost, s));
+  RDV_HIP(hipStreamSynchronize(s));
+  double t[EV_SLOTS] = {0};
+  for (size_t w = 0; w < waves; ++w)      // fixed order: reproducible sums
+    for (int j = 0; j <= EV_N; ++j) t[j] += h->host_eval[w * EV_SLOTS + j];
+  const double m = t[EV_N];
+  std::memset(out, 0, sizeof *out);
+  out->episodes = (int64_t)m;
+  out->ep_rew = t[EV_REW] / m; out->ep_len = t[EV_LEN] / m; out->ep_dist = t[EV_DIST] / m; out->ep_delta_v = t[EV_DV] / m;
+  out->ep_delta_w = t[EV_DW] / m; out->ep_success = t[EV_SUCC] / m; out->ep_collision_percentage = t[EV_COLLP] / m;
+  out->ep_time_of_first_collision = t[EV_TFIRST_N] > 0 ? t[EV_TFIRST] / t[EV_TFIRST_N] : -1.0;        // :274-282
+  out->ep_min_pos_error = t[EV_MINPOS_N] > 0 ? t[EV_MINPOS] / t[EV_MINPOS_N] : -1.0;
+  out->ep_avg_att_error = t[EV_AVGATT] / m;
+  out->pct_collided_episodes = t[EV_NCOLL] / m * 100.0; out->pct_successful_episodes = t[EV_NSUCC] / m * 100.0;   // :270-271
+  return RDV_OK;
 }
 
 int rdv_get_stats(rdv_handle h, RdvStats* out, int reset, void* stream) {

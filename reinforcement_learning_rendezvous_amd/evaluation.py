@@ -25,66 +25,44 @@ SUMMARY_KEYS = ["ep_rew", "ep_len", "ep_dist", "ep_delta_v", "ep_delta_w", "ep_s
                 "%_successfull_episodes"]          # custom_callbacks.py:285-298
 
 
+def episode_steps_bound(params):
+    """Steps after which every episode has ended: the first k with round(k * dt, 3) >= t_max (rendezvous_env.py:193, :368)."""
+    k = max(int(params.t_max / params.dt) - 3, 0)
+    while round(k * params.dt, 3) < params.t_max:
+        k += 1
+    return k
+
+
 @torch.no_grad()
 def evaluate_policy_batch(policy, env, deterministic=True, generator=None):
     """custom_callbacks.py:186-300 with every evaluation episode as one env of ``env`` (halt mode).
 
+    Nothing leaves the device inside the step loop: the per-step bookkeeping of the reference (:238-252 — attitude-error sum,
+    collision steps, time of the first one, smallest position error before it, reward) is accumulated per env by the step kernel
+    (``env.eval``, rdv_eval_begin), the loop runs for the number of steps after which every episode has ended (halted envs are
+    left untouched), and the twelve means are reduced on the device (``env.eval_summary``).
     Returns (summary, per_episode): the dict the reference logs, and the per-episode arrays it averages."""
     p = env.params
-    m = env.num_envs
     obs = env.reset()                                                    # :211
-    d = env.diagnose().cpu().numpy()
-    sum_att = d[:, 2].copy()                                             # :213
-    in_koz = d[:, 4] > 0                                                 # :214
-    collisions = in_koz.astype(np.float64)                               # :215-220
-    t_first = np.where(in_koz, 0.0, np.nan)
-    min_pos = np.where(in_koz, np.nan, d[:, 0])                          # :221-222
-    total_reward = np.zeros(m)
-    active = np.ones(m, dtype=bool)
-    k = 0
-    limit = int(p.t_max / p.dt) + 2
-    while active.any():                                                  # :227
-        k += 1
-        if k > limit:
-            raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
+    env.eval_begin()                                                     # :213-222, from the initial state
+    for _ in range(episode_steps_bound(p)):                              # :227 `while not done`, for all episodes at once
         actions = policy.act(obs, deterministic=deterministic, generator=generator)          # :230-235
-        obs, rew, done = env.step(actions.contiguous(), diag=True)                            # :238
-        dg = env.diag.cpu().numpy()
-        rw = rew.cpu().numpy().astype(np.float64)
-        dn = done.cpu().numpy().astype(bool)
-        t_now = round(k * p.dt, 3)
-        total_reward[active] += rw[active]                                                    # :242
-        sum_att[active] += dg[active, 2]                                                      # :243
-        koz = dg[:, 4] > 0                                                                    # :244
-        hit = active & koz
-        collisions[hit] += 1                                                                  # :246
-        first = hit & np.isnan(t_first)
-        t_first[first] = t_now                                                                # :247-248
-        free = active & ~koz & np.isnan(t_first)                                              # :249-252
-        min_pos[free] = np.fmin(min_pos[free], dg[free, 0])
-        active &= ~dn
+        obs, _, _ = env.step(actions.contiguous(), accumulate=True)                           # :238-252
+    if not bool(env.done.all()):
+        raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
+    summary = env.eval_summary()                                         # :254-298, wavefront reductions
+    acc = env.eval.cpu().numpy()                                         # one transfer, after the loop: the per-episode arrays
     aux = env.get_aux().cpu().numpy()
     state = env.get_state().cpu().numpy()
     end_time = aux[:, 0]                                                 # :254
     steps = end_time / p.dt                                              # :255
     per = {
-        "ep_rews": total_reward, "ep_end_times": end_time, "ep_dists": np.linalg.norm(state[:, 0:3], axis=1),     # :258-260
+        "ep_rews": acc[:, 0], "ep_end_times": end_time, "ep_dists": np.linalg.norm(state[:, 0:3], axis=1),         # :258-260
         "ep_delta_vs": aux[:, 4], "ep_delta_ws": aux[:, 5], "ep_successes": aux[:, 3],                             # :261-263
-        "ep_collision_percentages": collisions / steps * 100, "ep_times_of_first_collision": t_first,              # :264-265
-        "ep_min_pos_errors": min_pos, "ep_avg_att_errors": sum_att / (steps + 1),                                  # :266-267
+        "ep_collision_percentages": acc[:, 3] / steps * 100, "ep_times_of_first_collision": acc[:, 4],             # :264-265
+        "ep_min_pos_errors": acc[:, 5], "ep_avg_att_errors": acc[:, 2] / (steps + 1),                              # :266-267
     }
-    with_coll = int((collisions > 0).sum())                              # :268
-    with_succ = int((aux[:, 3] > 0).sum())                               # :269
-    summary = {
-        "ep_rew": per["ep_rews"].mean(), "ep_len": per["ep_end_times"].mean(), "ep_dist": per["ep_dists"].mean(),
-        "ep_delta_v": per["ep_delta_vs"].mean(), "ep_delta_w": per["ep_delta_ws"].mean(),
-        "ep_success": per["ep_successes"].mean(), "ep_collision_percentage": per["ep_collision_percentages"].mean(),
-        "ep_time_of_first_collision": -1 if np.all(np.isnan(t_first)) else np.nanmean(t_first),          # :274-282
-        "ep_min_pos_error": -1 if np.all(np.isnan(min_pos)) else np.nanmean(min_pos),
-        "ep_avg_att_error": per["ep_avg_att_errors"].mean(),
-        "%_collided_episodes": with_coll / m * 100, "%_successfull_episodes": with_succ / m * 100,
-    }
-    return {k_: float(v) for k_, v in summary.items()}, per
+    return {k_: float(summary[k_]) for k_ in SUMMARY_KEYS}, per
 
 
 def evaluate_policy(policy, n_evals=50, params=None, device="cuda:0", storage="f32", seed=0, deterministic=True,

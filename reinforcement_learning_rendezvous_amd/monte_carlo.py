@@ -67,63 +67,58 @@ def terminal_errors(errors, max_rd, max_vd, max_qd, max_wd):
     return (pos[index:].mean(), vel[index:].mean(), np.degrees(att[index:].mean()), np.degrees(rot[index:].mean()))
 
 
-@torch.no_grad()
-def evaluate_batch(policy, env, initial_states, deterministic=True, generator=None):
-    """monte_carlo.evaluate (:94-207) for every row of ``initial_states`` at once.
+def columns_from_accumulators(acc, aux, params):
+    """The reference's 12 output columns (monte_carlo.py:192-205) from the per-env evaluation accumulators (include/rdv.h,
+    rdv_eval_begin) and the bookkeeping: [M,32] and [M,8] float64 torch tensors (any device) or NumPy arrays -> dict of NumPy arrays.
 
-    ``env`` must hold ``len(initial_states)`` envs in halt mode; returns a dict of 12 float64 arrays (COLUMNS)."""
-    p = env.params
+    Terminal errors (:153-189): the mean of each error from the first step at which all four constraints held — else the first with
+    three, two, one — to the end; the kernel keeps {count, sums} per level from that level's first hit, so the mean is sum / count of
+    the strictest level that was ever hit (``terminal_errors`` is the same rule on an error history), and the last sample if none."""
+    acc, aux = torch.as_tensor(acc), torch.as_tensor(aux)
+    lv = acc[:, 12:32].reshape(-1, 4, 5)                                 # [M, level, {count, pos, vel, att, rot}]
+    hit = lv[:, :, 0] > 0
+    first = torch.argmax(hit.to(torch.int8), dim=1)                      # strictest level with a hit (argmax: first True)
+    pick = torch.gather(lv, 1, first.view(-1, 1, 1).expand(-1, 1, 5)).squeeze(1)
+    means = pick[:, 1:5] / pick[:, 0:1].clamp(min=1.0)
+    err = torch.where(hit.any(dim=1, keepdim=True), means, acc[:, 8:12])   # :177 index = -1: the last sample only
+    length = acc[:, 1]
+    cols = dict(ep_len=torch.round(length * params.dt, decimals=3), num_collisions=acc[:, 3], collided=(acc[:, 3] > 0).double(),
+                total_reward=acc[:, 0], total_delta_v=aux[:, 4], num_successes=acc[:, 6], succeeded=(acc[:, 6] > 0).double(),
+                min_dist_from_koz=acc[:, 7], pos_error=err[:, 0], vel_error=err[:, 1], att_error=torch.rad2deg(err[:, 2]),
+                rot_error=torch.rad2deg(err[:, 3]))
+    return {c: cols[c].cpu().numpy() for c in COLUMNS}
+
+
+def _normalised(initial_states):
     states = np.array(initial_states, dtype=np.float64, copy=True)
-    m = states.shape[0]
-    assert m == env.num_envs, (m, env.num_envs)
     states[:, 6:10] /= np.linalg.norm(states[:, 6:10], axis=1, keepdims=True)        # :66
     states[:, 13:17] /= np.linalg.norm(states[:, 13:17], axis=1, keepdims=True)      # :67
-    steps_max = int(p.t_max / p.dt) + 1                                              # :97
-    errors = np.full((m, 4, steps_max + 1), np.nan)
+    return states
+
+
+@torch.no_grad()
+def _run_episodes(policy, env, states, deterministic, generator=None, act=None):
+    """monte_carlo.evaluate (:94-207) for every row of ``states`` at once, nothing leaving the device inside the loop: the step
+    kernel accumulates the per-step bookkeeping of :117-150 per env (``env.eval``), the loop runs for the number of steps after
+    which every episode has ended, and the 12 columns are formed from the accumulators afterwards (one transfer)."""
+    from .evaluation import episode_steps_bound
+    p = env.params
+    assert states.shape[0] == env.num_envs, (states.shape[0], env.num_envs)
     env.reset()                                                                      # :106 (flags of the nominal state stay, :107-112)
     env.set_state(torch.from_numpy(states))
     obs = env.observe()                                                              # :113
-    d0 = env.diagnose().cpu().numpy()
-    errors[:, :, 0] = d0[:, 0:4]                                                     # :117
-    num_collisions = d0[:, 4].copy()                                                 # :119-120
-    num_successes = d0[:, 5].copy()                                                  # :121-122 (check_success is 0 once collided)
-    min_dist = d0[:, 6].copy()                                                       # :123
-    total_reward = np.zeros(m)
-    length = np.zeros(m, dtype=np.int64)
-    active = np.ones(m, dtype=bool)
-    k = 1
-    while active.any():                                                              # :126
-        if k > steps_max + 1:
-            raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
-        actions = policy.act(obs, deterministic=deterministic, generator=generator)  # :128-133
-        obs, rew, done = env.step(actions.contiguous(), diag=True)                   # :136
-        dg = env.diag.cpu().numpy()
-        rw = rew.cpu().numpy().astype(np.float64)
-        dn = done.cpu().numpy().astype(bool)
-        if k <= steps_max:
-            errors[active, :, k] = dg[active, 0:4]                                   # :140
-        num_collisions[active] += dg[active, 4]                                      # :142-144
-        num_successes[active] += dg[active, 5]                                       # :145-146
-        min_dist[active] = np.minimum(min_dist[active], dg[active, 6])               # :147-149
-        total_reward[active] += rw[active]                                           # :150
-        length[active] = k
-        active &= ~dn
-        k += 1
-    aux = env.get_aux().cpu().numpy()
-    out = {c: np.zeros(m) for c in COLUMNS}
-    out["ep_len"] = np.round(length * p.dt, 3)                                       # t[0,-1] with :193's rounding
-    out["num_collisions"] = num_collisions
-    out["collided"] = (num_collisions > 0).astype(np.float64)
-    out["total_reward"] = total_reward
-    out["total_delta_v"] = aux[:, 4]
-    out["num_successes"] = num_successes
-    out["succeeded"] = (num_successes > 0).astype(np.float64)
-    out["min_dist_from_koz"] = min_dist
-    for i in range(m):
-        e = errors[i, :, : length[i] + 1]
-        (out["pos_error"][i], out["vel_error"][i], out["att_error"][i], out["rot_error"][i]) = terminal_errors(
-            e, p.max_rd_error, p.max_vd_error, p.max_qd_error, p.max_wd_error)
-    return out
+    env.eval_begin()                                                                 # :117-123
+    for _ in range(episode_steps_bound(p)):                                          # :126
+        actions = act(obs) if act is not None else policy.act(obs, deterministic=deterministic, generator=generator)   # :128-133
+        obs, _, _ = env.step(actions.contiguous(), accumulate=True)                  # :136-150
+    if not bool(env.done.all()):
+        raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
+    return columns_from_accumulators(env.eval, env.get_aux(), p)
+
+
+def evaluate_batch(policy, env, initial_states, deterministic=True, generator=None):
+    """``env`` must hold ``len(initial_states)`` envs in halt mode; returns a dict of 12 float64 arrays (COLUMNS)."""
+    return _run_episodes(policy, env, _normalised(initial_states), deterministic, generator)
 
 
 def run(policy, initial_states, device="cuda:0", storage="f32", config=None, deterministic=True, seed=0,
@@ -145,49 +140,15 @@ def run(policy, initial_states, device="cuda:0", storage="f32", config=None, det
     return out
 
 
-REPLICA_COLUMNS = ["ep_len", "num_collisions", "collided", "total_reward", "total_delta_v", "num_successes", "succeeded",
-                   "min_dist_from_koz"]
+REPLICA_COLUMNS = COLUMNS          # the stochastic replicas keep all twelve columns (the terminal errors need no error history)
 
 
-@torch.no_grad()
 def evaluate_replicas(policy, env, states):
     """Stochastic-action trajectories (SB3 ``predict(deterministic=False)``: mean + exp(log_std) N(0,1), clipped) from the given
-    initial states, one per env of the halting batch ``env``; all bookkeeping of monte_carlo.evaluate (:117-150) stays on the
-    device.  Returns the first 8 output columns (the terminal-error columns need the whole error history: see evaluate_batch)."""
-    p = env.params
-    states = np.array(states, dtype=np.float64, copy=True)
-    m = states.shape[0]
-    assert m == env.num_envs, (m, env.num_envs)
-    states[:, 6:10] /= np.linalg.norm(states[:, 6:10], axis=1, keepdims=True)        # :66
-    states[:, 13:17] /= np.linalg.norm(states[:, 13:17], axis=1, keepdims=True)      # :67
-    steps_max = int(p.t_max / p.dt) + 1                                              # :97
-    env.reset()                                                                      # :106
-    env.set_state(torch.from_numpy(states))
-    obs = env.observe()                                                              # :113
-    d0 = env.diagnose()
-    num_collisions, num_successes, min_dist = d0[:, 4].clone(), d0[:, 5].clone(), d0[:, 6].clone()   # :119-123
-    total_reward = torch.zeros_like(min_dist)
-    length = torch.zeros(m, dtype=torch.int64, device=min_dist.device)
-    active = torch.ones(m, dtype=torch.bool, device=min_dist.device)
-    for k in range(1, steps_max + 2):                                                # :126
-        actions = policy.act(obs, deterministic=False)                               # :128-133 with deterministic=False
-        obs, rew, done = env.step(actions.contiguous(), diag=True)                   # :136
-        dg = env.diag
-        num_collisions += torch.where(active, dg[:, 4], 0.0)                         # :142-144
-        num_successes += torch.where(active, dg[:, 5], 0.0)                          # :145-146
-        min_dist = torch.where(active, torch.minimum(min_dist, dg[:, 6]), min_dist)  # :147-149
-        total_reward += torch.where(active, rew.double(), 0.0)                       # :150
-        length = torch.where(active, k, length)
-        active &= ~done.bool()
-        if not bool(active.any()):
-            break
-    else:
-        raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
-    aux = env.get_aux()
-    cols = dict(ep_len=torch.round(length.double() * p.dt, decimals=3), num_collisions=num_collisions,
-                collided=(num_collisions > 0).double(), total_reward=total_reward, total_delta_v=aux[:, 4],
-                num_successes=num_successes, succeeded=(num_successes > 0).double(), min_dist_from_koz=min_dist)
-    return {c: cols[c].cpu().numpy() for c in REPLICA_COLUMNS}
+    initial states, one per env of the halting batch ``env``, the exploration noise keyed by the batch's global env ids."""
+    offset = getattr(env, "env_id_offset", None)
+    act = (lambda obs: policy.act(obs, deterministic=False, env_id_offset=offset)) if offset is not None else None
+    return _run_episodes(policy, env, _normalised(states), False, act=act)
 
 
 def run_replicas(policy, initial_states, replicas, device="cuda:0", storage="f32", config=None, seed=0, rank=0, world=1,
@@ -207,7 +168,7 @@ def run_replicas(policy, initial_states, replicas, device="cuda:0", storage="f32
         policy = policy.to(env.device)
     else:
         env = engine_factory(hi - lo, params)
-    policy.noise_seed, policy.noise_env_offset, policy._calls = int(seed), lo, 0
+    policy.noise_seed, policy.noise_env_offset, policy._calls = int(seed), lo, 0      # (engines without env_id_offset: tests)
     out = evaluate_replicas(policy, env, ics[np.arange(lo, hi) % m])
     if hasattr(env, "close"):
         env.close()
