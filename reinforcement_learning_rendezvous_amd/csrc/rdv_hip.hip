@@ -469,21 +469,23 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     const bool to_reset = fin && resets;
     const unsigned long long m_reset = __ballot(to_reset);
     if (lane == 0) fin_mask[wv] = m_reset;
-    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-    store_step_outputs<true>(A, i, active, fin, r, e);
-    RDV_STAMP(3);
-    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
     // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores.  If an env of this wave resets,
-    // the rows stay in LDS: the service wave swaps in the reset observation and stores the block after the barrier.
+    // the rows stay in LDS: the service wave swaps in the reset observation and stores the block.
 #pragma unroll
     for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
-    wave_lds_fence();
-    if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
-    RDV_STAMP(4);
-    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
-    RDV_STAMP(5);
-    RDV_STAMP(6);
+    // The barrier comes HERE, as soon as the service waves have what they wait for (which envs ended, the observation rows), not at the
+    // end of the step wave: the statistics, the per-env outputs and the stores of the step wave (~1.1 us) then run beside the service
+    // waves' reset writes (~0.9 us) instead of in front of them (stamps: 5.7 -> ~5.0 us from the first wave's entry to the last exit).
+    RDV_STAMP(3);
     __syncthreads();
+    RDV_STAMP(4);
+    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+    store_step_outputs<true>(A, i, active, fin, r, e);
+    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+    if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
+    RDV_STAMP(5);
+    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
+    RDV_STAMP(6);
   } else {
     // ------------------------------------------------------------------ service waves
     V packed[7];               // the next initial state, already in storage layout: nothing is left to compute after the barrier
