@@ -82,7 +82,7 @@ def test_config3_step_many_equals_the_step_loop_at_65536():
 
 def test_config4_eight_shards_of_65536_equal_one_batch_of_524288():
     """The 8-GPU configuration rehearsed on one device: shard g = envs [g * 65,536, (g + 1) * 65,536) of the global batch, its
-    reset RNG keyed by global env id.  The big batch runs the fused kernel (+ refill_kernel), the shards the split kernel."""
+    reset RNG keyed by global env id.  The big batch runs the fused kernel (in-lane resets), the shards the split kernel."""
     G, T = 8, 32
     full = _batch(G * N3, storage="f32", seed=17)
     shards = [_batch(N3, storage="f32", seed=17, env_id_offset=g * N3) for g in range(G)]
