@@ -224,7 +224,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out_host, voi
 /* n_steps calls of rdv_step for an OPEN-LOOP action tape actions [n_steps,N,6] in ONE persistent launch: the env state stays in
  * registers between the steps and there is no launch boundary (~4 us per step at 65,536 envs instead of ~7.8).  out->obs
  * [n_steps,N,17], out->reward [n_steps,N], out->done [n_steps,N] and (nullable) out->done_reason [n_steps,N] are written; the
- * other members of RdvStepOut must be NULL.  N must be a multiple of 4.  Same results, final state and statistics as the loop. */
+ * other members of RdvStepOut must be NULL.  N must be a multiple of 4.  Same results, final state and statistics as the loop,
+ * general rigid bodies (rdv_set_rigid_body) included. */
 int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const RdvStepOut* out_host, void* stream);
 
 /* Direct state access as monte_carlo.py:107-112 does (flags/aux are deliberately left untouched).
@@ -307,6 +308,7 @@ int rdv_policy_value(rdv_policy critic, const float* obs, float* values, int64_t
  * env time in) with the actor above, writing the rows SB3's RolloutBuffer.add receives.  Results are those of
  * rdv_policy_act(counter = noise_counter0 + t, env_id_offset = the handle's) followed by rdv_step, n_steps times; the env
  * state stays in registers and the observations / actions in LDS in between.  Episode statistics accumulate as in rdv_step.
+ * General rigid bodies (rdv_set_rigid_body) are integrated inside the launch as rdv_step does.
  */
 typedef struct RdvRolloutOut {
   float*   obs;        /* [T,N,17] required: the observation the actor saw at step t (buffer.observations) */

@@ -1019,7 +1019,6 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   if ((reinterpret_cast<uintptr_t>(out->obs) & 15) || (reinterpret_cast<uintptr_t>(out->actions) & 15) || (reinterpret_cast<uintptr_t>(out->last_obs) & 15))
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: obs, actions and last_obs must be 16-byte aligned");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: call rdv_reset first (state is undefined until reset(), as in the reference)");
-  if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_policy_act + rdv_step");
   DeviceGuard guard(h->device);
   h->raw_state = false;   // the rollout kernel integrates injected (unnormalised) quaternions itself
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1031,8 +1030,14 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   A.env_id_offset = h->env_id_offset; A.noise_seed = noise_seed; A.noise_counter0 = noise_counter0;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps; A.deterministic = deterministic ? 1 : 0;
   const dim3 grid((unsigned)((h->n + kRollEnvs - 1) / kRollEnvs)), block(kRollBlock);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(rollout_kernel<float>, grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
-  else hipLaunchKernelGGL(rollout_kernel<double>, grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
+  const bool f32 = h->storage == RDV_STORAGE_F32;
+  if (h->general) {
+    if (f32) hipLaunchKernelGGL((rollout_kernel<float, true>), grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
+    else hipLaunchKernelGGL((rollout_kernel<double, true>), grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
+  } else {
+    if (f32) hipLaunchKernelGGL((rollout_kernel<float, false>), grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
+    else hipLaunchKernelGGL((rollout_kernel<double, false>), grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
+  }
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
@@ -1084,10 +1089,17 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   }
   if (err == hipSuccess) { what = "hipMemcpy of the parameter block"; err = hipMemcpy(h->dev_params, &h->dev, sizeof(DevParams), hipMemcpyHostToDevice); }
   // the persistent kernels use more dynamic LDS than the 64 KiB default limit; raised here, outside any stream capture
-  if (err == hipSuccess) { what = "hipFuncSetAttribute(rollout_kernel<float>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, roll_lds_bytes<float>()); }
-  if (err == hipSuccess) { what = "hipFuncSetAttribute(rollout_kernel<double>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(rollout_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, roll_lds_bytes<double>()); }
-  if (err == hipSuccess) { what = "hipFuncSetAttribute(step_many_kernel<float>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<float>()); }
-  if (err == hipSuccess) { what = "hipFuncSetAttribute(step_many_kernel<double>, MaxDynamicSharedMemorySize)"; err = hipFuncSetAttribute(reinterpret_cast<const void*>(step_many_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, many_lds_bytes<double>()); }
+  auto raise_lds = [&](const void* fn, int bytes, const char* name) {
+    if (err == hipSuccess) { what = name; err = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+  };
+  raise_lds(reinterpret_cast<const void*>(rollout_kernel<float, false>), roll_lds_bytes<float>(), "hipFuncSetAttribute(rollout_kernel<float>, MaxDynamicSharedMemorySize)");
+  raise_lds(reinterpret_cast<const void*>(rollout_kernel<double, false>), roll_lds_bytes<double>(), "hipFuncSetAttribute(rollout_kernel<double>, MaxDynamicSharedMemorySize)");
+  raise_lds(reinterpret_cast<const void*>(rollout_kernel<float, true>), roll_lds_bytes<float>(), "hipFuncSetAttribute(rollout_kernel<float, general>, MaxDynamicSharedMemorySize)");
+  raise_lds(reinterpret_cast<const void*>(rollout_kernel<double, true>), roll_lds_bytes<double>(), "hipFuncSetAttribute(rollout_kernel<double, general>, MaxDynamicSharedMemorySize)");
+  raise_lds(reinterpret_cast<const void*>(step_many_kernel<float, false>), many_lds_bytes<float>(), "hipFuncSetAttribute(step_many_kernel<float>, MaxDynamicSharedMemorySize)");
+  raise_lds(reinterpret_cast<const void*>(step_many_kernel<double, false>), many_lds_bytes<double>(), "hipFuncSetAttribute(step_many_kernel<double>, MaxDynamicSharedMemorySize)");
+  raise_lds(reinterpret_cast<const void*>(step_many_kernel<float, true>), many_lds_bytes<float>(), "hipFuncSetAttribute(step_many_kernel<float, general>, MaxDynamicSharedMemorySize)");
+  raise_lds(reinterpret_cast<const void*>(step_many_kernel<double, true>), many_lds_bytes<double>(), "hipFuncSetAttribute(step_many_kernel<double, general>, MaxDynamicSharedMemorySize)");
   if (err != hipSuccess) {
     (void)hipGetLastError();
     if (h->own_ws) (void)hipFree(h->ws);
@@ -1304,7 +1316,6 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if (out->terminal_obs || out->episode_return || out->episode_length || out->diag || out->eval)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: terminal_obs, episode_return, episode_length, diag and eval are outputs of rdv_step only");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: call rdv_reset first (state is undefined until reset(), as in the reference)");
-  if (h->general) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: general rigid bodies (rdv_set_rigid_body) are stepped with rdv_step");
   if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions and obs must be 16-byte aligned");
   if ((h->n & 3) != 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: n_envs must be a multiple of 4 (rows of [K,N,17] / [K,N,6] start 16-byte aligned)");
@@ -1318,8 +1329,14 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   A.prep = h->prep; A.prep_tag = h->prep_tag;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps;
   const dim3 grid((unsigned)((h->n + kManyEnvs - 1) / kManyEnvs)), block(kManyBlock);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(step_many_kernel<float>, grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
-  else hipLaunchKernelGGL(step_many_kernel<double>, grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
+  const bool f32 = h->storage == RDV_STORAGE_F32;
+  if (h->general) {
+    if (f32) hipLaunchKernelGGL((step_many_kernel<float, true>), grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
+    else hipLaunchKernelGGL((step_many_kernel<double, true>), grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
+  } else {
+    if (f32) hipLaunchKernelGGL((step_many_kernel<float, false>), grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
+    else hipLaunchKernelGGL((step_many_kernel<double, false>), grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
+  }
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }

@@ -69,7 +69,8 @@ struct RolloutArgs {
   int32_t deterministic;
 };
 
-template <typename ST>
+// kGeneral: general rigid bodies (rdv_set_rigid_body) — both attitudes by the reference's RK45 scheme per lane, as in step_kernel.
+template <typename ST, bool kGeneral = false>
 __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __restrict__ Pp, const float* __restrict__ W,
                                                              const RolloutArgs A) {
   using V = typename Vec4<ST>::type;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   const int64_t env_rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
   Env e;
   e.episode = 0u;
-  bool wt_dirty = false;
+  bool wt_dirty = kGeneral;  // the target's rate is constant between resets for the reference's bodies, not for general ones
   bool slot_dirty = false;   // this env's slot in LDS differs from the one in HBM
   const SlotStore<ST> H = hbm_slot_store<ST>(A.prep);   // the slots in HBM
   uint64_t* my_stats = stat_lds + (wv & (kRollEnvWaves - 1)) * kStatWords;
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #pragma unroll
       for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[sl * RDV_ACT_DIM + j] : 0.0f;
       StepResult r;
-      const bool stepped = advance<ST, false, false, true>(SA, P, it, active, e, a, r);   // kRaw: a rollout may start from an injected state
+      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, it, active, e, a, r);   // kRaw: a rollout may start from an injected state
       const bool fin = stepped && r.done;
       if (active) {
         A.reward[(int64_t)t * n + it] = r.reward;

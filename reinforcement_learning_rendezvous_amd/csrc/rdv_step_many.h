@@ -45,7 +45,8 @@ struct StepManyArgs {
   int32_t n_steps;
 };
 
-template <typename ST>
+// kGeneral: general rigid bodies (rdv_set_rigid_body) — both attitudes by the reference's RK45 scheme per lane, as in step_kernel.
+template <typename ST, bool kGeneral = false>
 __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* __restrict__ Pp, const StepManyArgs A) {
   using V = typename Vec4<ST>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     Env e;
     e.episode = 0u;
     bool slot_dirty = false;   // this env's slot in LDS differs from the one in HBM
-    bool wt_dirty = false;
+    bool wt_dirty = kGeneral;  // the target's rate is constant between resets for the reference's bodies, not for general ones
     if (active) load_env<ST>(ws, n, i, e);
     if (resets) {
       uint32_t tag = 0u;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
       for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? my_act[lane * RDV_ACT_DIM + j] : 0.0f;
       if (rows > 0 && k + 1 < K) fetch(k + 1, pre);
       StepResult r;
-      const bool stepped = advance<ST, false, false, true>(SA, P, i, active, e, a, r);   // kRaw: the tape may start from an injected state
+      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, i, active, e, a, r);   // kRaw: the tape may start from an injected state
       const bool fin = stepped && r.done;
       if (active) {
         const int64_t o = (int64_t)k * n + i;

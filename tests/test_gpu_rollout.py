@@ -129,9 +129,6 @@ def test_rollout_argument_checks():
     env.reset()
     with pytest.raises(RdvError, match="n_steps"):
         env.rollout(pol, 0)
-    env.set_rigid_body(inertia_target=[9.0, 16.0, 27.0])
-    with pytest.raises(RdvError, match="general rigid bodies"):
-        env.rollout(pol, 4)
     env.close(); pol.close()
 
 
@@ -177,9 +174,6 @@ def test_step_many_argument_checks():
     env.reset()
     with pytest.raises(ValueError):
         env.step_many(torch.zeros((4, 63, 6), device="cuda:0"))
-    env.set_rigid_body(inertia_target=[9.0, 16.0, 27.0])
-    with pytest.raises(RdvError, match="general rigid bodies"):
-        env.step_many(tape)
     env.close()
     odd = _batch(66)
     odd.reset()

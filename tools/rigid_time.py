@@ -36,5 +36,26 @@ for name, body in cases:
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 256
-    print(f"{name:48s}: {us:8.2f} us per step, {n / us * 1e-3:8.3f} G env steps/s at n={n}", flush=True)
-    env.close()
+    # the same bodies inside the persistent kernels: an open-loop tape (rdv_step_many) and the closed loop (rdv_rollout)
+    tape = torch.stack(acts * 8).contiguous()                       # [64, n, 6]
+    out = env.step_many(tape)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        env.step_many(tape, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    us_many = e0.elapsed_time(e1) * 1e3 / 256
+    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+    pol = MlpPolicy.from_npz(os.path.join(ROOT, "tests", "golden", "mlp_policy.npz")).to("cuda:0")
+    ro = env.rollout(pol, 64, deterministic=False)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(4):
+        env.rollout(pol, 64, deterministic=False, out=ro)
+    e1.record()
+    torch.cuda.synchronize()
+    us_roll = e0.elapsed_time(e1) * 1e3 / 256
+    print(f"{name:48s}: rdv_step {us:8.2f} us per step ({n / us * 1e-3:6.3f} G env steps/s) | rdv_step_many {us_many:8.2f} us "
+          f"({n / us_many * 1e-3:6.3f} G) | rdv_rollout {us_roll:8.2f} us ({n / us_roll * 1e-3:6.3f} G) at n={n}", flush=True)
+    pol.close(); env.close()
