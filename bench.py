@@ -254,8 +254,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "achieved_from_traffic": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
-                         "kernel": ("rdv::step_kernel_split" + ("<float>" if args.storage == "f32" else "<double>")) if n <= 98304 else
-                                   ("rdv::step_kernel" + ("<float,false,false,false>" if args.storage == "f32" else "<double,false,false,false>")),
+                         "kernel": ("rdv::step_kernel_split" + ("<float>" if args.storage == "f32" else "<double>")) if n <= 65536 else
+                                   ("rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>")),
                          "launch_us": launch_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "achieved = 293 B x envs per launch / launch_us.  At 65,536 envs the 15 MB working set stays in the 256 MiB "
                                  "Infinity Cache between launches (FETCH/WRITE_SIZE count fabric requests, MALL hits included): the HBM "
@@ -309,7 +309,7 @@ def main():
             ach = ALGO_BYTES_PER_ENV_STEP * n_big / (us_big * 1e-6) / 1e9
             tr = pmc.get(f"{args.storage}_{n_big}")
             out["large_n"] = {"value": n_big / (us_big * 1e-6), "unit": "env steps/s", "envs": n_big, "launch_us": us_big,
-                              "kernel": "rdv::step_kernel" + ("<float,false,false,false>" if args.storage == "f32" else "<double,false,false,false>"),
+                              "kernel": "rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>"),
                               "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
                                            "traffic": tr["bytes_per_launch"] if tr else None,
                                            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" if tr else None},

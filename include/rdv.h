@@ -61,12 +61,14 @@ typedef enum RdvOnDone {
                               reports done again and counts as a finished episode in the statistics */
 } RdvOnDone;
 
-/* Which step kernel rdv_step launches.  Both give the same results (same arithmetic); they differ in how the work of a
- * step is laid out on the chip.  AUTO picks SPLIT while the batch leaves SIMDs idle (n_envs <= 98304) and FUSED above. */
+/* Which step kernel rdv_step launches.  All give the same results (same arithmetic); they differ in how the work of a
+ * step is laid out on the chip.  AUTO picks SPLIT up to one 256-env workgroup per CU (n_envs <= 65536) and FUSED above. */
 typedef enum RdvKernelVariant {
   RDV_VARIANT_AUTO = 0,
-  RDV_VARIANT_FUSED = 1,  /* one wave does everything for its 64 envs, resets run divergently in-lane */
-  RDV_VARIANT_SPLIT = 2   /* step waves + service waves that precompute every env's next initial state beside them */
+  RDV_VARIANT_FUSED = 1,  /* one wave does the transition of its 64 envs; the workgroup's four waves share the resets of its finished envs by part */
+  RDV_VARIANT_SPLIT = 2,  /* step waves + service waves that precompute every env's next initial state beside them */
+  RDV_VARIANT_FUSED_INLANE = 3  /* as FUSED, but every finished lane runs its whole reset itself (divergent); also what the evaluator
+                                   build (diag / eval outputs), general rigid bodies and the first step after rdv_set_state run */
 } RdvKernelVariant;
 
 /*

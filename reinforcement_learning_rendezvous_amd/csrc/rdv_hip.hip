@@ -33,7 +33,7 @@ constexpr int kBlock = 256;             // 4 waves per workgroup
 constexpr int kWave = 64;
 constexpr int kChunks = 7;
 constexpr int kStatWords = 16;          // 128-byte slot per wave
-constexpr int64_t kSplitAutoMaxEnvs = 98304;    // measured crossover (tools/n_sweep.py): split wins while the chip is not full
+constexpr int64_t kSplitAutoMaxEnvs = 65536;    // measured crossover (tools/n_sweep.py, profiles/r02_n_sweep_parts.csv): split wins up to one 256-env workgroup per CU
 enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
        ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
 
@@ -404,6 +404,77 @@ __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __rest
   if (i >= A.n) return;
   const V c5 = reinterpret_cast<const V*>(A.ws)[5 * A.n + i];
   refill_whole<ST>(A, *Pp, i, s2u(c5.w));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused variant with the reset shared BY PART inside the workgroup (training build: no diagnostics, reference bodies, normalised
+// state).  Everything up to the reset is step_kernel; a lane whose episode ended lists its env in LDS instead of resetting it, and
+// after a workgroup barrier the four waves write the resets of the listed envs (~13 of 256 with random actions) together — wave w
+// does part w (rc+vc+bookkeeping | qc+wc | qt | wt: reset_fields<ST, kPart>) for all of them, ~13 active lanes, straight into the
+// envs' state chunks in HBM and their observation rows in LDS (LiveStore) — then a second barrier and the coalesced row stores.
+// The in-lane form runs the whole ~900-instruction reset with ~3 active lanes in 96 % of the waves: about half of that kernel's
+// vector instructions (SQ_INSTS_VALU 1,645 per wave, profiles/r02_sq_counters_4M.csv), and at three waves per SIMD they are not
+// hidden.  Here every wave issues one part (~150-350 instructions) and the four stay balanced — unlike the variant that left the
+// whole resets to the workgroup's last wave (profiles/r02_n_sweep_compacted_reset.csv), which held a wave slot and the LDS for a
+// lone serial chain.  Same expressions on the same inputs: bit-identical results.  (Forced to 128 VGPRs for four waves per SIMD it
+// spills 16 dwords and loses: 342 against 315 us at 4.2 M envs.)
+template <typename ST>
+__global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+                                                             uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
+  StepArgs A = A_rest;
+  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
+  using V = typename Vec4<ST>::type;
+  __shared__ __attribute__((aligned(16))) float lds[kBlock * RDV_OBS_DIM];   // observation rows [256][17]; before that, per wave, the action rows
+  __shared__ uint32_t job_kind[kBlock];
+  __shared__ uint32_t job_counter[kBlock];
+  __shared__ uint16_t lists[kGroupWaves * kBlock];
+  static_assert(kBlock == kGroupEnvs, "refill_pass_lds is written for 256-env workgroups");
+  const DevParams& P = *Pp;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave_in_block = threadIdx.x >> 6;
+  const int64_t block_base = (int64_t)blockIdx.x * kBlock;
+  const int64_t i = block_base + threadIdx.x;
+  const int64_t wave_base = i - lane;
+  const int64_t n = A.n;
+  const bool active = i < n;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
+  V* ws = reinterpret_cast<V*>(A.ws);
+  const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform: the barriers below are executed by all waves or by none
+
+  {
+    Env e;
+    if (active) load_env<ST>(ws, n, i, e);
+    uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
+    const uint64_t slot_pre = stats_preload(slot, lane);
+    float a[RDV_ACT_DIM];
+    load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+    StepResult r;
+    const bool stepped = advance<ST, false, false, false>(A, P, i, active, e, a, r);
+    const bool fin = stepped && r.done;
+    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+    store_step_outputs<true>(A, i, active, fin, r, e);
+    const bool to_reset = fin && resets;
+    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+#pragma unroll
+    for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
+    if (resets) {
+      job_kind[threadIdx.x] = to_reset ? JOB_REFILL : JOB_NONE;
+      job_counter[threadIdx.x] = e.episode;
+    }
+    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // a listed env's state is written by the parts, all seven chunks
+  }
+  if (resets) {
+    __syncthreads();   // the workgroup's finished envs are listed, every observation row is staged
+    LiveStore<ST> L;
+    L.ws = ws; L.rows = lds; L.n = n; L.base = block_base;
+    refill_pass_lds<ST>(wave_in_block, lane, P, L, job_kind, job_counter, lists + wave_in_block * kBlock, block_base, n, A.seed,
+                        A.env_id_offset, A.tape, A.tape_depth);
+    __syncthreads();   // SB3 DummyVecEnv semantics: the rows of the listed envs now hold the first observation of the next episode
+  } else {
+    wave_lds_fence();
+  }
+  store_obs_rows(A.obs, wave_base, rows, lane, wl);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1230,7 +1301,7 @@ int rdv_debug_set_stamps(rdv_handle h, unsigned long long* stamps) {   // diagno
 #endif
 int rdv_set_kernel_variant(rdv_handle h, int variant) {
   RDV_CHECK_HANDLE(h);
-  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT)
+  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT && variant != RDV_VARIANT_FUSED_INLANE)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_kernel_variant: bad variant %d", variant);
   h->variant = variant;
   return RDV_OK;
@@ -1297,6 +1368,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
     } else if (raw) {
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true, false, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false, false, true>), grid, block); }
       else { if (dg) RDV_LAUNCH((step_kernel<double, true, false, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false, false, true>), grid, block); }
+    } else if (!dg && h->variant != RDV_VARIANT_FUSED_INLANE) {
+      if (f32) RDV_LAUNCH(step_kernel_parts<float>, grid, block); else RDV_LAUNCH(step_kernel_parts<double>, grid, block);
     } else {
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false>), grid, block); }
       else { if (dg) RDV_LAUNCH((step_kernel<double, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false>), grid, block); }

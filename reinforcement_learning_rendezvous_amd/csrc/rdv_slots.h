@@ -33,8 +33,24 @@ struct SlotStore {
   typename Vec4<ST>::type* chunks;
   float4* obs;
   int64_t cs, es, ocs, oes;
+  static constexpr bool kLive = false;
   __device__ __forceinline__ typename Vec4<ST>::type* chunk(int c, int64_t i) const { return chunks + (c * cs + i * es); }
   __device__ __forceinline__ float4* ovec(int v, int64_t i) const { return obs + (v * ocs + i * oes); }
+  __device__ __forceinline__ float* oelem(int j, int64_t i) const { return reinterpret_cast<float*>(ovec(j >> 2, i)) + (j & 3); }
+  __device__ __forceinline__ void opad(int64_t i) const { float* p = oelem(16, i); p[1] = 0.0f; p[2] = 0.0f; p[3] = 0.0f; }
+};
+// The same interface over an env's LIVE state: entry s of a workgroup is env base + s, its chunks are the state arrays in HBM, its
+// observation the row s of the workgroup's staged rows [256][17] in LDS.  A reset by part written through this store IS the reset
+// (step_kernel: the fused one-launch kernel's in-workgroup reset), not a preparation of the next one.
+template <typename ST>
+struct LiveStore {
+  typename Vec4<ST>::type* ws;
+  float* rows;
+  int64_t n, base;
+  static constexpr bool kLive = true;
+  __device__ __forceinline__ typename Vec4<ST>::type* chunk(int c, int64_t s) const { return ws + (c * n + base + s); }
+  __device__ __forceinline__ float* oelem(int j, int64_t s) const { return rows + (s * RDV_OBS_DIM + j); }
+  __device__ __forceinline__ void opad(int64_t) const {}
 };
 template <typename ST> constexpr int slot_record_bytes() { return sizeof(ST) == 4 ? 192 : 320; }
 template <typename ST>
@@ -120,8 +136,9 @@ __device__ __forceinline__ void reset_whole(const DevParams& P, Env& ne, float* 
 //   RESET_RC_VC : rc, vc, the bookkeeping (bubble, totals, episode return, step count, flags, episode index), obs[0..5]
 //   RESET_QC_WC : qc, wc, obs[6..12]          RESET_QT : qt, obs[13..16]          RESET_WT : wt
 // The flags of an initial state (:261-262) need all of it: see kFlagsPending.
-template <typename ST, int kPart>
-__device__ __forceinline__ void slot_refill_part(const DevParams& P, const SlotStore<ST>& S, int64_t i, uint64_t seed, uint64_t env_id,
+// (A live store has nobody to defer them to: there the rc+vc part derives the other fields too in that case and evaluates them.)
+template <typename ST, int kPart, typename Store>
+__device__ __forceinline__ void slot_refill_part(const DevParams& P, const Store& S, int64_t i, uint64_t seed, uint64_t env_id,
                                                  uint32_t counter, const double* tape_row) {
   const ST t = ST(0);
   Env ne;
@@ -129,12 +146,18 @@ __device__ __forceinline__ void slot_refill_part(const DevParams& P, const SlotS
   reset_fields<ST, kPart>(P, ne, seed, env_id, tape_row);
   ST* c1 = reinterpret_cast<ST*>(S.chunk(1, i));
   ST* c2 = reinterpret_cast<ST*>(S.chunk(2, i));
-  float* o0 = reinterpret_cast<float*>(S.ovec(0, i));
-  float* o1 = reinterpret_cast<float*>(S.ovec(1, i));
-  float* o2 = reinterpret_cast<float*>(S.ovec(2, i));
-  float* o3 = reinterpret_cast<float*>(S.ovec(3, i));
+  auto O = [&](int j) -> float& { return *S.oelem(j, i); };
   if (kPart == RESET_RC_VC) {
-    const uint32_t flags = reset_flags_needed(P, ne) ? kFlagsPending : 0u;
+    uint32_t flags = 0u;
+    if (reset_flags_needed(P, ne)) {
+      flags = kFlagsPending;
+      if (Store::kLive) {
+        Env full;
+        full.episode = counter;
+        reset_fields<ST, RESET_ALL>(P, full, seed, env_id, tape_row);
+        flags = reset_flags(P, full);
+      }
+    }
     typename Vec4<ST>::type v0, v5;
     v0.x = (ST)ne.rc[0]; v0.y = (ST)ne.rc[1]; v0.z = (ST)ne.rc[2]; v0.w = (ST)ne.vc[0];
     *S.chunk(0, i) = v0;
@@ -146,32 +169,32 @@ __device__ __forceinline__ void slot_refill_part(const DevParams& P, const SlotS
     for (int j = 0; j < 3; ++j) {
       const float a = normalized(ne.rc[j], P.obs_lo_r, P.obs_span_r, P.obs_inv_span_r);
       const float b = normalized(ne.vc[j], P.obs_lo_v, P.obs_span_v, P.obs_inv_span_v);
-      o0[j] = a;
-      if (j == 0) o0[3] = b; else o1[j - 1] = b;
+      O(j) = a;
+      O(3 + j) = b;
     }
   } else if (kPart == RESET_QC_WC) {
     typename Vec4<ST>::type v3;
     v3.x = (ST)ne.qc[0]; v3.y = (ST)ne.qc[1]; v3.z = (ST)ne.qc[2]; v3.w = (ST)ne.qc[3];
     *S.chunk(3, i) = v3;
     c1[2] = (ST)ne.wc[0]; c1[3] = (ST)ne.wc[1]; c2[0] = (ST)ne.wc[2];
-    o1[2] = (float)ne.qc[0]; o1[3] = (float)ne.qc[1]; o2[0] = (float)ne.qc[2]; o2[1] = (float)ne.qc[3];
-    o2[2] = normalized(ne.wc[0], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
-    o2[3] = normalized(ne.wc[1], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
-    o3[0] = normalized(ne.wc[2], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
+    O(6) = (float)ne.qc[0]; O(7) = (float)ne.qc[1]; O(8) = (float)ne.qc[2]; O(9) = (float)ne.qc[3];
+    O(10) = normalized(ne.wc[0], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
+    O(11) = normalized(ne.wc[1], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
+    O(12) = normalized(ne.wc[2], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
   } else if (kPart == RESET_QT) {
     typename Vec4<ST>::type v4;
     v4.x = (ST)ne.qt[0]; v4.y = (ST)ne.qt[1]; v4.z = (ST)ne.qt[2]; v4.w = (ST)ne.qt[3];
     *S.chunk(4, i) = v4;
-    o3[1] = (float)ne.qt[0]; o3[2] = (float)ne.qt[1]; o3[3] = (float)ne.qt[2];
-    *S.ovec(4, i) = make_float4((float)ne.qt[3], 0.0f, 0.0f, 0.0f);
+    O(13) = (float)ne.qt[0]; O(14) = (float)ne.qt[1]; O(15) = (float)ne.qt[2]; O(16) = (float)ne.qt[3];
+    S.opad(i);
   } else {
     typename Vec4<ST>::type v6;
     v6.x = (ST)ne.wt[0]; v6.y = (ST)ne.wt[1]; v6.z = (ST)ne.wt[2]; v6.w = ST(0);
     *S.chunk(6, i) = v6;
   }
 }
-template <typename ST>
-__device__ __forceinline__ void slot_refill_role(int role, const DevParams& P, const SlotStore<ST>& S, int64_t i, uint64_t seed,
+template <typename ST, typename Store>
+__device__ __forceinline__ void slot_refill_role(int role, const DevParams& P, const Store& S, int64_t i, uint64_t seed,
                                                  uint64_t env_id, uint32_t counter, const double* tape_row) {
   // `role` is wave-uniform (the wave's index among the refilling waves): one of four straight-line code paths per wave
   if (role == 0) slot_refill_part<ST, RESET_RC_VC>(P, S, i, seed, env_id, counter, tape_row);
@@ -202,9 +225,10 @@ __device__ __forceinline__ int compact_flags(const bool (&flag)[Q], int lane, ui
 constexpr int kGroupEnvs = 256;
 constexpr int kGroupWaves = kGroupEnvs / kWave;   // 4: the waves that share a refill by part
 
-// One refill pass of a service wave over the jobs the env lanes listed (job_kind != 0), for its part `role` of the slots in LDS.
-template <typename ST>
-__device__ __forceinline__ void refill_pass_lds(int role, int lane, const DevParams& P, const SlotStore<ST>& L, const uint32_t* job_kind,
+// One refill pass of a service wave over the jobs the env lanes listed (job_kind != 0), for its part `role` of the slots in LDS
+// (or of the live states: LiveStore).
+template <typename ST, typename Store>
+__device__ __forceinline__ void refill_pass_lds(int role, int lane, const DevParams& P, const Store& L, const uint32_t* job_kind,
                                                 const uint32_t* job_counter, uint16_t* list, int64_t block_base, int64_t n, uint64_t seed,
                                                 uint64_t env_id_offset, const double* tape, int32_t tape_depth) {
   bool flag[kGroupWaves];

@@ -65,7 +65,7 @@ def test_random_parameter_sets(case):
     rng = np.random.default_rng(1000 + case)
     p = _random_params(rng)
     n = int(rng.choice([96, 300, 777]))
-    for variant in ("fused", "split"):
+    for variant in ("fused", "split", "fused_inlane"):
         for storage in ("f32", "f64"):
             for on_done in ("reset", "halt"):
                 env = _batch(n, params=p, storage=storage, on_done=on_done, seed=case, variant=variant)
@@ -81,7 +81,7 @@ def test_large_attitude_steps_take_the_angle_halving_path():
     """dt = 20 s with body rates up to ~9 deg/s: |w| dt/2 up to ~1.6 rad, beyond the small-angle polynomial (u > 0.62)."""
     p = make_params(dt=20.0, t_max=400.0, wt0=np.radians([4.0, -6.0, 5.0]), wt0_range=float(np.radians(2.0)), qt0_range=float(np.radians(170)))
     n = 256
-    for variant in ("fused", "split"):
+    for variant in ("fused", "split", "fused_inlane"):
         env = _batch(n, params=p, storage="f64", seed=3, variant=variant)
         orc = oracle.OracleBatch(n, to_oracle_params(p), seed=3, storage=oracle.STORAGE_F64)
         np.testing.assert_allclose(_np(env.reset()), orc.reset(), rtol=0, atol=1.2e-7)
@@ -95,7 +95,7 @@ def test_states_inside_the_keep_out_zone_and_parameter_updates():
     (nominal position inside max(koz, |rd| + max_rd)); then reward coefficients changed mid-run (tune_reward.py)."""
     p = make_params(rc0=np.array([0.0, -2.2, 0.0]), rc0_range=1.5, qt0_range=float(np.radians(60)), t_max=30)
     n = 512
-    for variant in ("fused", "split"):
+    for variant in ("fused", "split", "fused_inlane"):
         env = _batch(n, params=p, storage="f32", seed=21, variant=variant)
         orc = oracle.OracleBatch(n, to_oracle_params(p), seed=21, storage=oracle.STORAGE_F32)
         np.testing.assert_allclose(_np(env.reset()), orc.reset(), rtol=0, atol=1.2e-7)

@@ -62,16 +62,18 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"n{c['n']}-{c['storage']}-{'-'.join(c['kw']) or 'default'}")
 def test_step_layouts_and_persistent_kernels_agree(case):
-    """rdv_step in its two layouts, rdv_step_many and rdv_rollout's env phase (driven through step_many's tape here) on parameter
+    """rdv_step in its three layouts, rdv_step_many and rdv_rollout's env phase (driven through step_many's tape here) on parameter
     sets that reset often, every step, or into states whose collided / success flags are set at reset: observations, rewards,
     dones, reasons, terminal observations, episode returns / lengths, state, bookkeeping, statistics."""
     n, storage, T = case["n"], case["storage"], 60
     p = make_params(**case["kw"])
     ref = _batch(n, params=p, storage=storage, seed=21, variant="fused")
     other = _batch(n, params=p, storage=storage, seed=21, variant="split")
+    inlane = _batch(n, params=p, storage=storage, seed=21, variant="fused_inlane")
     many = _batch(n - n % 4, params=p, storage=storage, seed=21)
     o0 = ref.reset().clone()
     _same(o0, other.reset(), "split: reset obs")
+    _same(o0, inlane.reset(), "in-lane: reset obs")
     _same(o0[: n - n % 4], many.reset(), "step_many: reset obs")
     acts = [torch.from_numpy(counter_actions(4, t, n)).cuda() for t in range(T)]
     n_done = 0
@@ -83,10 +85,13 @@ def test_step_layouts_and_persistent_kernels_agree(case):
         n_done += int(want["done"].sum())
         other.step(acts[t])
         _assert_same_step(want, _step_outputs(other), t, "split")
+        inlane.step(acts[t])
+        _assert_same_step(want, _step_outputs(inlane), t, "in-lane")
     assert n_done > n // 2
-    _same(ref.get_state(), other.get_state(), "split: state")
-    _same(ref.get_aux(), other.get_aux(), "split: aux")
-    assert ref.get_stats() == other.get_stats()
+    for name, b in (("split", other), ("in-lane", inlane)):
+        _same(ref.get_state(), b.get_state(), f"{name}: state")
+        _same(ref.get_aux(), b.get_aux(), f"{name}: aux")
+        assert ref.get_stats() == b.get_stats(), name
     # the same tape through the persistent kernel, in three launches with single steps in between (the slots are re-derived)
     m = n - n % 4
     t = 0
@@ -102,10 +107,10 @@ def test_step_layouts_and_persistent_kernels_agree(case):
                     _same(out[k_][j], outs[t + j][key][:m], f"step_many: {k_}, step {t + j}")
         t += K
     _same(ref.get_state()[:m], many.get_state(), "step_many: state")
-    ref.close(); other.close(); many.close()
+    ref.close(); other.close(); inlane.close(); many.close()
 
 
-@pytest.mark.parametrize("variant", ["fused", "split"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
 def test_training_kernels_vs_oracle_with_philox_resets(storage, variant):
     """The training kernels themselves (no diagnostics) against the CPU oracle: config-2 shape, shortened; plus parameters
@@ -134,7 +139,7 @@ def test_training_kernels_vs_oracle_with_philox_resets(storage, variant):
         env.close()
 
 
-@pytest.mark.parametrize("variant", ["fused", "split"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
 def test_training_kernels_replay_the_reference_tape(variant):
     """Reset tape (the initial states the unmodified reference drew) through the training kernels (no diagnostics)."""
     g = load_golden("steps_A_random.npz")
