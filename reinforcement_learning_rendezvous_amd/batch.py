@@ -45,19 +45,19 @@ class RendezvousBatch:
         nbytes = self._lib.rdv_workspace_bytes(self.num_envs, self.storage)
         if nbytes <= 0:
             raise N.RdvError(-1, f"bad num_envs/storage: {num_envs}, {storage}")
-        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)   # caching allocator: 512-B aligned
+        self._ws = self._alloc("workspace", (nbytes,), torch.uint8)   # caching allocator: 512-B aligned
         N.check(self._lib.rdv_create(C.byref(self.params), self.num_envs, dev_index, self.storage, self.on_done,
                                      C.c_uint64(seed), C.c_uint64(env_id_offset), self._ws.data_ptr(),
                                      C.byref(self._h)))
         N.check(self._lib.rdv_set_kernel_variant(self._h, _VARIANT[variant]))
         n, dev = self.num_envs, self.device
-        self.obs = torch.zeros((n, N.OBS_DIM), dtype=torch.float32, device=dev)
-        self.reward = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.done = torch.zeros(n, dtype=torch.uint8, device=dev)
-        self.terminal_obs = torch.zeros((n, N.OBS_DIM), dtype=torch.float32, device=dev)
-        self.episode_return = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.episode_length = torch.zeros(n, dtype=torch.int32, device=dev)
-        self.done_reason = torch.zeros(n, dtype=torch.uint8, device=dev)
+        self.obs = self._alloc("obs", (n, N.OBS_DIM), torch.float32)
+        self.reward = self._alloc("reward", (n,), torch.float32)
+        self.done = self._alloc("done", (n,), torch.uint8)
+        self.terminal_obs = self._alloc("terminal_obs", (n, N.OBS_DIM), torch.float32)
+        self.episode_return = self._alloc("episode_return", (n,), torch.float32)
+        self.episode_length = self._alloc("episode_length", (n,), torch.int32)
+        self.done_reason = self._alloc("done_reason", (n,), torch.uint8)
         self.diag = None
         self.eval = None
         self._tape = None
@@ -67,6 +67,10 @@ class RendezvousBatch:
         self._outs = {}
 
     # ------------------------------------------------------------------------------------------------ plumbing
+    def _alloc(self, name, shape, dtype):
+        """Device buffers of the batch (zero-filled); one place, so that a caller with its own arena can override it."""
+        return torch.zeros(shape, dtype=dtype, device=self.device)
+
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 

@@ -2,7 +2,7 @@
 """Builds profiles/pmc_traffic.json from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE collected in SEPARATE runs, as
 MI355X_MICROARCH.md prescribes: the two counters do not fit one pass; FETCH_SIZE x2 for 16-byte-per-lane streams on gfx950).
 
-    python tools/pmc_to_json.py gpurun_out/pmc_r02      # expects <dir>/<key>_FETCH_SIZE/p_counter_collection.csv, ..._WRITE_SIZE/...
+    python tools/pmc_to_json.py gpurun_out/refresh/pmc [profiles/rNN_pmc_summary.csv]      # expects <dir>/<key>_FETCH_SIZE/p_counter_collection.csv, ..._WRITE_SIZE/...
 
 key = <storage>_<n_envs> for rdv_step, step_many_<storage>_<n>_K64, rollout_<storage>_<n>_T64 (tools/step_once.py, persistent_once.py)."""
 import collections
@@ -50,6 +50,19 @@ def main():
         out[key] = rec
         print(key, name, f"{rec['bytes_per_launch'] / 1e6:.2f} MB per launch, {rec['bytes_per_env_step']:.1f} B per env-step")
     json.dump(out, open(out_path, "w"), indent=1)
+    # the per-pass summary that goes with it (profiles/rNN_pmc_summary.csv): every kernel of every pass, mean after the first two
+    if len(sys.argv) > 2:
+        with open(sys.argv[2], "w") as fh:
+            fh.write("workload,kernel,counter,dispatches,mean_KiB_after_first_two\n")
+            for sub in sorted(x for x in os.listdir(d) if x.endswith("_SIZE")):
+                counter = sub.rsplit("_", 2)[1] + "_SIZE"
+                by = collections.defaultdict(list)
+                for r in csv.DictReader(open(os.path.join(d, sub, "p_counter_collection.csv"))):
+                    if "rdv::" in r["Kernel_Name"]:
+                        by[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+                for k, v in sorted(by.items()):
+                    if len(v) > 2:
+                        fh.write(f'{sub},"{k}",{counter},{len(v)},{sum(v[2:]) / len(v[2:]):.3f}\n')
 
 
 if __name__ == "__main__":

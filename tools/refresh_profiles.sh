@@ -1,0 +1,35 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): the measurements profiles/ is built from.
+#   1. bench.py (default flags, and the driver's --steps 20 --warmup 5)             -> gpurun_out/refresh/bench_*.json
+#   2. rocprofv3 --kernel-trace --stats of the default bench command                 -> gpurun_out/refresh/kstats/
+#   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per workload        -> gpurun_out/refresh/pmc/<key>_<COUNTER>/
+# Counters are collected without any other trace domain (only --kernel-trace), the program after `--` is python3 itself.
+set -o pipefail
+R=$(pwd)
+OUT=$R/gpurun_out/refresh
+rm -rf "$OUT"; mkdir -p "$OUT/pmc"
+export TMPDIR=/tmp
+timeout -k 10 400 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || exit 1
+echo "bench default done"
+timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2> "$OUT/bench_driver_flags.err" || exit 1
+echo "bench driver flags done"
+cd /tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kstats" -o p -- python3 "$R/bench.py" > "$OUT/bench_profiled.json" 2> "$OUT/bench_profiled.err" || exit 1
+echo "kernel stats done"
+pmc() {   # key, script, args...
+  local key=$1; shift
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc/${key}_$c" -o p -- python3 "$@" > "$OUT/pmc/${key}_$c.log" 2>&1 || return 1
+  done
+  echo "pmc $key done"
+}
+pmc f32_65536 "$R/tools/step_once.py" 65536 auto 8 f32 &&
+pmc f64_65536 "$R/tools/step_once.py" 65536 auto 8 f64 &&
+pmc f32_4194304 "$R/tools/step_once.py" 4194304 auto 8 f32 &&
+pmc persist "$R/tools/persistent_once.py"
+# one run holds both persistent kernels: tools/pmc_to_json.py picks each by name from a directory per key
+for c in FETCH_SIZE WRITE_SIZE; do
+  cp -r "$OUT/pmc/persist_$c" "$OUT/pmc/step_many_f32_65536_K64_$c" && mv "$OUT/pmc/persist_$c" "$OUT/pmc/rollout_f32_65536_T64_$c" || exit 1
+done
+find "$OUT" -name "*.csv" -size +20M -delete      # kernel traces of the long bench run are not needed, the stats are
+echo "refresh complete"
