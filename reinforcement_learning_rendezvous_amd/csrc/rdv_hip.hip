@@ -33,6 +33,14 @@ constexpr int kBlock = 256;             // 4 waves per workgroup
 constexpr int kWave = 64;
 constexpr int kChunks = 7;
 constexpr int kStatWords = 16;          // 128-byte slot per wave
+// Fused kernels: each XCD walks a contiguous eighth of the batch (instead of every 8th workgroup of the whole batch) when the batch
+// is a multiple of 65,536 envs up to 3 M — an empirical rule (tools/xcd_map_ab.py, profiles/r02_xcd_order_ab.txt; order toggled per
+// launch on one allocation): -10 % at 524,288 envs (42.2 -> 37.8 us), -9 % at 786,432, -7 % at 262,144, -5 % at 1 M, -3 % at 196,608
+// and 2 M, -1 % at 3 M; +2 % at 4 M, +3.5 % at 8 M; and off those sizes it does not pay: +8 % at 1,000,000, +6 % at 262,400, -4 % at
+// 528,384, 0 at 500,000.  Padding or skewing the arrays instead changes nothing (chunk_stride).  RDV_XCD_ORDER=0|1 in the
+// environment at rdv_create forces it off / on (diagnostics).
+constexpr int64_t kXcdOrderMaxEnvs = 3145728;
+static inline bool xcd_order_by_size(int64_t n) { return n <= kXcdOrderMaxEnvs && n % 65536 == 0; }
 constexpr int64_t kSplitAutoMaxEnvs = 65536;    // measured crossover (tools/n_sweep.py, profiles/r02_n_sweep_parts.csv): split wins up to one 256-env workgroup per CU
 enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
        ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
@@ -47,10 +55,10 @@ __device__ __forceinline__ uint32_t s2u(float s) { return __float_as_uint(s); }
 __device__ __forceinline__ uint32_t s2u(double s) { return (uint32_t)__double_as_longlong(s); }
 
 template <typename ST>
-__device__ __forceinline__ void load_env(const typename Vec4<ST>::type* __restrict__ ws, int64_t n, int64_t i, Env& e) {
+__device__ __forceinline__ void load_env(const typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i, Env& e) {
   using V = typename Vec4<ST>::type;
-  const V c0 = ws[0 * n + i], c1 = ws[1 * n + i], c2 = ws[2 * n + i], c3 = ws[3 * n + i], c4 = ws[4 * n + i],
-          c5 = ws[5 * n + i], c6 = ws[6 * n + i];
+  const V c0 = ws[0 * cs + i], c1 = ws[1 * cs + i], c2 = ws[2 * cs + i], c3 = ws[3 * cs + i], c4 = ws[4 * cs + i],
+          c5 = ws[5 * cs + i], c6 = ws[6 * cs + i];
   e.rc[0] = c0.x; e.rc[1] = c0.y; e.rc[2] = c0.z; e.vc[0] = c0.w;
   e.vc[1] = c1.x; e.vc[2] = c1.y; e.wc[0] = c1.z; e.wc[1] = c1.w;
   e.wc[2] = c2.x; e.bubble = c2.y; e.sum_dv = c2.z; e.sum_dw = c2.w;
@@ -73,17 +81,17 @@ __device__ __forceinline__ void pack_env(const Env& e, typename Vec4<ST>::type* 
   c[6].x = (ST)e.wt[0]; c[6].y = (ST)e.wt[1]; c[6].z = (ST)e.wt[2]; c[6].w = ST(0);
 }
 template <typename ST>
-__device__ __forceinline__ void store_chunks(typename Vec4<ST>::type* __restrict__ ws, int64_t n, int64_t i,
+__device__ __forceinline__ void store_chunks(typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i,
                                              const typename Vec4<ST>::type* c, bool with_wt) {
 #pragma unroll
-  for (int k = 0; k < 6; ++k) ws[k * n + i] = c[k];
-  if (with_wt) ws[6 * n + i] = c[6];
+  for (int k = 0; k < 6; ++k) ws[k * cs + i] = c[k];
+  if (with_wt) ws[6 * cs + i] = c[6];
 }
 template <typename ST>
-__device__ __forceinline__ void store_env(typename Vec4<ST>::type* __restrict__ ws, int64_t n, int64_t i, const Env& e, bool with_wt) {
+__device__ __forceinline__ void store_env(typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i, const Env& e, bool with_wt) {
   typename Vec4<ST>::type c[7];
   pack_env<ST>(e, c);
-  store_chunks<ST>(ws, n, i, c, with_wt);
+  store_chunks<ST>(ws, cs, i, c, with_wt);
 }
 
 // Diagnostic build only (-DRDV_STAMPS, tools/stamp_profile.py): s_memtime stamps at the phase boundaries of the split
@@ -122,12 +130,14 @@ struct StepArgs {
   double* eval;             // nullable [N,32]: per-env evaluation accumulators (eval_accumulate)
   const double* tape;       // nullable [depth][N][20]
   int64_t n;
+  int64_t cs;               // chunk stride in envs: chunk c of env i is vector c * cs + i of the workspace (chunk_stride)
   uint64_t seed;
   uint64_t env_id_offset;
   int32_t tape_depth;
   int32_t on_done;
   void* prep;               // prepared next-episode states of the persistent kernels (csrc/rdv_slots.h): one record per env
   uint32_t* prep_tag;       // [N]
+  int32_t xcd_per;          // step_kernel_parts: workgroups per XCD region (0: plain block order)
 #ifdef RDV_STAMPS
   unsigned long long* stamps;
 #endif
@@ -338,7 +348,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   const DevParams& P = *Pp;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave_in_block = threadIdx.x >> 6;
-  const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int64_t lblock = A.xcd_per ? (int64_t)(blockIdx.x & 7) * A.xcd_per + (blockIdx.x >> 3) : (int64_t)blockIdx.x;   // XCD order: see step_kernel_parts
+  const int64_t i = lblock * kBlock + threadIdx.x;
   const int64_t wave_base = i - lane;
   const int64_t n = A.n;
   const bool active = i < n;
@@ -347,9 +358,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   V* ws = reinterpret_cast<V*>(A.ws);
 
   Env e;
-  if (active) load_env<ST>(ws, n, i, e);   // 7 x 16-byte-per-lane loads, issued before anything depends on them
+  if (active) load_env<ST>(ws, A.cs, i, e);   // 7 x 16-byte-per-lane loads, issued before anything depends on them
   uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-  const uint64_t slot_pre = stats_preload(slot, lane);
+  const uint64_t slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;
   float a[RDV_ACT_DIM];
   load_actions(A.actions, wave_base, rows, lane, active, wl, a);
 
@@ -377,7 +388,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   wave_lds_fence();
   store_obs_rows(A.obs, wave_base, rows, lane, wl);
   // state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt, or always when wt evolves)
-  if (stepped) store_env<ST>(ws, n, i, e, did_reset || kGeneral);
+  if (stepped) store_env<ST>(ws, A.cs, i, e, did_reset || kGeneral);
 }
 
 }  // namespace rdv
@@ -402,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __rest
   using V = typename Vec4<ST>::type;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= A.n) return;
-  const V c5 = reinterpret_cast<const V*>(A.ws)[5 * A.n + i];
+  const V c5 = reinterpret_cast<const V*>(A.ws)[5 * A.cs + i];
   refill_whole<ST>(A, *Pp, i, s2u(c5.w));
 }
 
@@ -432,7 +443,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
   const DevParams& P = *Pp;
   const int lane = threadIdx.x & (kWave - 1);
   const int wave_in_block = threadIdx.x >> 6;
-  const int64_t block_base = (int64_t)blockIdx.x * kBlock;
+  // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); with A.xcd_per != 0 XCD x walks its own
+  // contiguous eighth of the envs in ascending order instead of every 8th workgroup of the whole batch (see kXcdOrderMaxEnvs)
+  const int64_t lblock = A.xcd_per ? (int64_t)(blockIdx.x & 7) * A.xcd_per + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+  const int64_t block_base = lblock * kBlock;
   const int64_t i = block_base + threadIdx.x;
   const int64_t wave_base = i - lane;
   const int64_t n = A.n;
@@ -444,9 +458,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
 
   {
     Env e;
-    if (active) load_env<ST>(ws, n, i, e);
+    if (active) load_env<ST>(ws, A.cs, i, e);
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-    const uint64_t slot_pre = stats_preload(slot, lane);
+    const uint64_t slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;   // (a padding workgroup of the XCD order has no envs)
     float a[RDV_ACT_DIM];
     load_actions(A.actions, wave_base, rows, lane, active, wl, a);
     StepResult r;
@@ -462,12 +476,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
       job_kind[threadIdx.x] = to_reset ? JOB_REFILL : JOB_NONE;
       job_counter[threadIdx.x] = e.episode;
     }
-    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // a listed env's state is written by the parts, all seven chunks
+    if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);   // a listed env's state is written by the parts, all seven chunks
   }
   if (resets) {
     __syncthreads();   // the workgroup's finished envs are listed, every observation row is staged
     LiveStore<ST> L;
-    L.ws = ws; L.rows = lds; L.n = n; L.base = block_base;
+    L.ws = ws; L.rows = lds; L.cs = A.cs; L.base = block_base;
     refill_pass_lds<ST>(wave_in_block, lane, P, L, job_kind, job_counter, lists + wave_in_block * kBlock, block_base, n, A.seed,
                         A.env_id_offset, A.tape, A.tape_depth);
     __syncthreads();   // SB3 DummyVecEnv semantics: the rows of the listed envs now hold the first observation of the next episode
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     float* wl = stage + wv * (kWave * RDV_OBS_DIM);
     Env e;
     StepResult r;
-    if (active) load_env<ST>(ws, n, i, e);
+    if (active) load_env<ST>(ws, A.cs, i, e);
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
     const uint64_t slot_pre = stats_preload(slot, lane);
     float a[RDV_ACT_DIM];
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
     if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
     RDV_STAMP(5);
-    if (stepped && !to_reset) store_env<ST>(ws, n, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
+    if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
     RDV_STAMP(6);
   } else {
     // ------------------------------------------------------------------ service waves
@@ -563,7 +577,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     float robs[RDV_OBS_DIM];
     if (resets && active) {
       Env ne;
-      const V c5 = ws[5 * n + i];
+      const V c5 = ws[5 * A.cs + i];
       ne.episode = s2u(c5.w);
       RDV_STAMP(1);
       const double* row = nullptr;
@@ -582,7 +596,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
       if (active && ((m_reset >> lane) & 1ull)) {
         // auto-reset (SB3 DummyVecEnv semantics): the new state to HBM, the first observation of the next episode into the row
-        store_chunks<ST>(ws, n, i, packed, true);
+        store_chunks<ST>(ws, A.cs, i, packed, true);
 #pragma unroll
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
       }
@@ -607,11 +621,11 @@ __global__ __launch_bounds__(kBlock) void reset_kernel(const DevParams* __restri
   V* ws = reinterpret_cast<V*>(A.ws);
   if (mask && !mask[i]) return;
   Env e;
-  load_env<ST>(ws, n, i, e);
+  load_env<ST>(ws, A.cs, i, e);
   if (fresh) e.episode = 0;   // first reset after create/seed: the workspace may hold anything
   const uint32_t counter = e.episode;
   reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, tape_row_of(A.tape, A.tape_depth, n, i, counter));
-  store_env<ST>(ws, n, i, e, true);
+  store_env<ST>(ws, A.cs, i, e, true);
   if (obs) {
     float o[RDV_OBS_DIM];
     observation(P, e, o);
@@ -624,20 +638,20 @@ enum { ACC_SET_STATE = 0, ACC_GET_STATE, ACC_GET_AUX, ACC_OBSERVE, ACC_DIAGNOSE,
 
 // state access / evaluator helpers (cold paths; one lane per env, row-major host-facing arrays)
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void* ws_, int64_t n, int what, const double* in,
+__global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void* ws_, int64_t n, int64_t cs, int what, const double* in,
                                                         double* out, float* out_f32) {
   using V = typename Vec4<ST>::type;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n) return;
   V* ws = reinterpret_cast<V*>(ws_);
   Env e;
-  load_env<ST>(ws, n, i, e);
+  load_env<ST>(ws, cs, i, e);
   const ST tag = ST(0);
   if (what == ACC_SET_STATE) {          // monte_carlo.py:107-112: the 20 state reals only; flags and aux stay
     const double* s = in + i * RDV_STATE_DIM;
     for (int j = 0; j < 3; ++j) { e.rc[j] = canon(s[j], tag); e.vc[j] = canon(s[3 + j], tag); e.wc[j] = canon(s[10 + j], tag); e.wt[j] = canon(s[17 + j], tag); }
     for (int j = 0; j < 4; ++j) { e.qc[j] = canon(s[6 + j], tag); e.qt[j] = canon(s[13 + j], tag); }
-    store_env<ST>(ws, n, i, e, true);
+    store_env<ST>(ws, cs, i, e, true);
   } else if (what == ACC_GET_STATE) {
     double* s = out + i * RDV_STATE_DIM;
     for (int j = 0; j < 3; ++j) { s[j] = e.rc[j]; s[3 + j] = e.vc[j]; s[10 + j] = e.wc[j]; s[17 + j] = e.wt[j]; }
@@ -668,7 +682,7 @@ __global__ __launch_bounds__(kBlock) void access_kernel(const DevParams P, void*
 // host adds the slots in index order.
 enum { EV_REW = 0, EV_LEN, EV_DIST, EV_DV, EV_DW, EV_SUCC, EV_COLLP, EV_TFIRST, EV_TFIRST_N, EV_MINPOS, EV_MINPOS_N, EV_AVGATT, EV_NCOLL, EV_NSUCC, EV_N, EV_SLOTS = 16 };
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void eval_summary_kernel(const DevParams P, const void* ws_, int64_t n, const double* eval, double* partial) {
+__global__ __launch_bounds__(kBlock) void eval_summary_kernel(const DevParams P, const void* ws_, int64_t n, int64_t cs, const double* eval, double* partial) {
   using V = typename Vec4<ST>::type;
   const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
   const int lane = threadIdx.x & (kWave - 1);
@@ -677,7 +691,7 @@ __global__ __launch_bounds__(kBlock) void eval_summary_kernel(const DevParams P,
   for (int j = 0; j <= EV_N; ++j) v[j] = 0.0;
   if (i < n) {
     Env e;
-    load_env<ST>(reinterpret_cast<const V*>(ws_), n, i, e);
+    load_env<ST>(reinterpret_cast<const V*>(ws_), cs, i, e);
     const double* acc = eval + i * kEvalDim;
     const double end_time = rint((double)e.k * P.dt * 1e3) / 1e3;      // :254
     const double steps = end_time / P.dt;                              // :255
@@ -739,7 +753,18 @@ static int fail(int code, const char* fmt, ...) {
 
 static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * a; }
 static inline int64_t n_waves(int64_t n) { return (n + kBlock - 1) / kBlock * (kBlock / kWave); }
-static inline int64_t chunk_bytes(int64_t n, int storage) { return align_up(kChunks * n * 4 * (storage == RDV_STORAGE_F64 ? 8 : 4), 256); }
+// Chunk stride (in envs): chunk c of env i is vector c * stride + i of the workspace.  The seven chunk arrays are walked in
+// lockstep, and every BASELINE size puts them a power of two apart; padding each array to 64 KiB / 2 MiB and offsetting neighbours by
+// 4 ... 260 KiB was measured and changes nothing at any size (tools/chunk_skew_sweep.py, profiles/r02_chunk_skew.txt), so the arrays
+// lie back to back.  RDV_CHUNK_ALIGN / RDV_CHUNK_SKEW (bytes, multiples of 256) in the environment set a padded spacing for that tool.
+static inline int64_t chunk_stride(int64_t n, int storage) {
+  static const int64_t align = [] { const char* x = getenv("RDV_CHUNK_ALIGN"); const long long v = x ? atoll(x) : 0; return (int64_t)(v >= 256 && v % 256 == 0 ? v : 0); }();
+  static const int64_t skew = [] { const char* x = getenv("RDV_CHUNK_SKEW"); const long long v = x ? atoll(x) : 0; return (int64_t)(v >= 0 && v % 256 == 0 ? v : 0); }();
+  if (align == 0) return n;
+  const int64_t vb = 4 * (storage == RDV_STORAGE_F64 ? 8 : 4);
+  return (align_up(n * vb, align) + skew) / vb;
+}
+static inline int64_t chunk_bytes(int64_t n, int storage) { return align_up(kChunks * chunk_stride(n, storage) * 4 * (storage == RDV_STORAGE_F64 ? 8 : 4), 256); }
 static inline int64_t stats_bytes(int64_t n) { return align_up(n_waves(n) * kStatWords * (int64_t)sizeof(uint64_t), 256); }
 static inline int64_t params_bytes() { return align_up((int64_t)sizeof(DevParams), 256); }
 constexpr int kAcosEntries = 200001;   // acos(k/1e5), k = -100000..100000 (general.py:179 rounds every cosine to 5 decimals)
@@ -858,6 +883,8 @@ struct RdvEnvBatch {
   const double* tape;
   int32_t tape_depth;
   int variant;       // RdvKernelVariant
+  int64_t cs;        // chunk stride in envs (chunk_stride)
+  int xcd_order;     // fused kernels' block order: -1 by size (xcd_order_by_size), 0 plain, 1 XCD-contiguous
   RdvRigidBody body; // rdv_set_rigid_body
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
   bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
@@ -880,7 +907,7 @@ static void apply_rigid_body(RdvEnvBatch* h);
 // the arguments every env kernel shares (the callers add their I/O pointers)
 static void base_args(const RdvEnvBatch* h, StepArgs& A) {
   std::memset(&A, 0, sizeof A);
-  A.ws = h->ws; A.stats = h->stats; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
+  A.ws = h->ws; A.stats = h->stats; A.tape = h->tape; A.n = h->n; A.cs = h->cs; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.prep = h->prep; A.prep_tag = h->prep_tag;
 }
 static inline dim3 grid_for(int64_t n) { return dim3((unsigned)((n + kBlock - 1) / kBlock)); }
@@ -1096,7 +1123,7 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   if (int rc = ensure_prepared(h, s)) return rc;
   RolloutArgs A;
   A.ws = h->ws; A.stats = h->stats; A.obs = out->obs; A.actions = out->actions; A.reward = out->reward; A.done = out->done;
-  A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.seed = h->seed;
+  A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.cs = h->cs; A.seed = h->seed;
   A.prep = h->prep; A.prep_tag = h->prep_tag;
   A.env_id_offset = h->env_id_offset; A.noise_seed = noise_seed; A.noise_counter0 = noise_counter0;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps; A.deterministic = deterministic ? 1 : 0;
@@ -1132,8 +1159,9 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   (void)rdv_rigid_body_default(&h->body); h->general = false; apply_rigid_body(h);
   h->raw_state = false;
 
-  h->n = n_envs; h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
+  h->n = n_envs; h->cs = chunk_stride(n_envs, storage); h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
+  { const char* x = getenv("RDV_XCD_ORDER"); h->xcd_order = (x && (x[0] == '0' || x[0] == '1') && !x[1]) ? x[0] - '0' : -1; }
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
   if (workspace) { h->ws = workspace; h->own_ws = false; }
   else {
@@ -1361,7 +1389,11 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
     const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
     if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
   } else {
-    const dim3 grid = grid_for(h->n), block(kBlock);
+    dim3 grid = grid_for(h->n), block(kBlock);
+    if (h->xcd_order == 1 || (h->xcd_order < 0 && xcd_order_by_size(h->n))) {
+      A.xcd_per = (int32_t)((grid.x + 7) / 8);
+      grid = dim3((unsigned)A.xcd_per * 8u);   // up to 7 padding workgroups, which find no envs
+    }
     if (h->general) {
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false, true>), grid, block); }
       else { if (dg) RDV_LAUNCH((step_kernel<double, true, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false, true>), grid, block); }
@@ -1398,7 +1430,7 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if (int rc = ensure_prepared(h, s)) return rc;
   StepManyArgs A;
   A.ws = h->ws; A.stats = h->stats; A.actions = actions; A.obs = out->obs; A.reward = out->reward; A.done = out->done;
-  A.done_reason = out->done_reason; A.tape = h->tape; A.n = h->n; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
+  A.done_reason = out->done_reason; A.tape = h->tape; A.n = h->n; A.cs = h->cs; A.seed = h->seed; A.env_id_offset = h->env_id_offset;
   A.prep = h->prep; A.prep_tag = h->prep_tag;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps;
   const dim3 grid((unsigned)((h->n + kManyEnvs - 1) / kManyEnvs)), block(kManyBlock);
@@ -1417,8 +1449,8 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
 static int access(rdv_handle h, int what, const double* in, double* out, float* out_f32, void* stream) {
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(access_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
-  else hipLaunchKernelGGL(access_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, what, in, out, out_f32);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(access_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, h->cs, what, in, out, out_f32);
+  else hipLaunchKernelGGL(access_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, h->cs, what, in, out, out_f32);
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
@@ -1517,8 +1549,8 @@ int rdv_eval_summary(rdv_handle h, const double* eval, RdvEvalSummary* out, void
   if (!eval || !out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_eval_summary: null accumulators / output");
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(eval_summary_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, eval, h->eval_partial);
-  else hipLaunchKernelGGL(eval_summary_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, eval, h->eval_partial);
+  if (h->storage == RDV_STORAGE_F32) hipLaunchKernelGGL(eval_summary_kernel<float>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, h->cs, eval, h->eval_partial);
+  else hipLaunchKernelGGL(eval_summary_kernel<double>, grid_for(h->n), dim3(kBlock), 0, s, h->dev, h->ws, h->n, h->cs, eval, h->eval_partial);
   RDV_HIP(hipGetLastError());
   const size_t waves = (size_t)((h->n + kWave - 1) / kWave);
   h->host_eval.resize(waves * EV_SLOTS);

@@ -59,6 +59,7 @@ struct RolloutArgs {
   void* prep;               // prepared next-episode states in HBM (rdv_slots.h)
   uint32_t* prep_tag;
   int64_t n;
+  int64_t cs;               // chunk stride of the workspace in envs
   uint64_t seed;            // reset RNG (as rdv_step)
   uint64_t env_id_offset;
   uint64_t noise_seed;      // exploration noise: Philox key; counter = noise_counter0 + t (as rdv_policy_act)
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #pragma unroll
     for (int j = 0; j < RDV_OBS_DIM; ++j) o[j] = 0.0f;
     if (active) {
-      load_env<ST>(reinterpret_cast<const V*>(A.ws), n, i, e);
+      load_env<ST>(reinterpret_cast<const V*>(A.ws), A.cs, i, e);
       observation(P, e, o);
     }
 #pragma unroll
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
    //  its 51 registers would be saved to scratch around it)
     // ---- the observation after the last step, the state, the slots that changed and the statistics go back to HBM
     store_obs_rows(A.last_obs, wave_base, env_rows, lane, obs_cur + (slot - lane) * RDV_OBS_DIM);
-    if (active) store_env<ST>(reinterpret_cast<V*>(A.ws), n, i, e, wt_dirty);
+    if (active) store_env<ST>(reinterpret_cast<V*>(A.ws), A.cs, i, e, wt_dirty);
     if (active && slot_dirty) {
       slot_copy<ST>(H, i, L, slot);
       A.prep_tag[i] = e.episode + 1u;

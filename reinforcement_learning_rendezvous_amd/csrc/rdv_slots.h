@@ -46,9 +46,9 @@ template <typename ST>
 struct LiveStore {
   typename Vec4<ST>::type* ws;
   float* rows;
-  int64_t n, base;
+  int64_t cs, base;   // chunk stride of the workspace, first env of the workgroup
   static constexpr bool kLive = true;
-  __device__ __forceinline__ typename Vec4<ST>::type* chunk(int c, int64_t s) const { return ws + (c * n + base + s); }
+  __device__ __forceinline__ typename Vec4<ST>::type* chunk(int c, int64_t s) const { return ws + (c * cs + base + s); }
   __device__ __forceinline__ float* oelem(int j, int64_t s) const { return rows + (s * RDV_OBS_DIM + j); }
   __device__ __forceinline__ void opad(int64_t) const {}
 };

@@ -38,6 +38,7 @@ struct StepManyArgs {
   void* prep;               // prepared next-episode states in HBM (rdv_slots.h)
   uint32_t* prep_tag;
   int64_t n;
+  int64_t cs;               // chunk stride of the workspace in envs
   uint64_t seed;
   uint64_t env_id_offset;
   int32_t tape_depth;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     e.episode = 0u;
     bool slot_dirty = false;   // this env's slot in LDS differs from the one in HBM
     bool wt_dirty = kGeneral;  // the target's rate is constant between resets for the reference's bodies, not for general ones
-    if (active) load_env<ST>(ws, n, i, e);
+    if (active) load_env<ST>(ws, A.cs, i, e);
     if (resets) {
       uint32_t tag = 0u;
       if (active) { tag = A.prep_tag[i]; slot_copy<ST>(L, slot, H, i); }
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
       store_obs_rows(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs);
       wave_lds_fence();   // the rows are rewritten by the next step
     }
-    if (active) store_env<ST>(ws, n, i, e, wt_dirty);
+    if (active) store_env<ST>(ws, A.cs, i, e, wt_dirty);
     if (resets) {
       __syncthreads();   // F: the slots taken in the last step have been refilled
       if (active && slot_dirty) {

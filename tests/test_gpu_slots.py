@@ -272,3 +272,34 @@ def test_stochastic_rollout_and_act_are_shard_invariant():
         e.close()
     for p in pols:
         p.close()
+
+
+def test_xcd_contiguous_block_order_gives_the_same_results(monkeypatch):
+    """The fused kernels' XCD-contiguous block order (on by size for multiples of 65,536 envs; forced here with RDV_XCD_ORDER on a
+    ragged size, where the grid is padded with workgroups that find no envs) only changes which workgroup handles which envs."""
+    n, T = 5 * 256 + 77, 40
+    p = make_params(t_max=12.0)
+    envs = {}
+    for order in ("0", "1"):
+        monkeypatch.setenv("RDV_XCD_ORDER", order)
+        envs[order] = [_batch(n, params=p, storage="f32", seed=8, variant=v) for v in ("fused", "fused_inlane")]
+    monkeypatch.delenv("RDV_XCD_ORDER")
+    ref = envs["0"][0]
+    others = [envs["0"][1]] + envs["1"]
+    o0 = ref.reset().clone()
+    for b in others:
+        _same(o0, b.reset(), "reset obs")
+    for t in range(T):
+        a = torch.from_numpy(counter_actions(6, t, n)).cuda()
+        ref.step(a)
+        want = _step_outputs(ref)
+        for k, b in enumerate(others):
+            b.step(a)
+            _assert_same_step(want, _step_outputs(b), t, f"batch {k}")
+    for b in others:
+        _same(ref.get_state(), b.get_state(), "state")
+        _same(ref.get_aux(), b.get_aux(), "aux")
+        assert ref.get_stats() == b.get_stats()
+        b.close()
+    assert ref.get_stats()["episodes"] > n
+    ref.close()
