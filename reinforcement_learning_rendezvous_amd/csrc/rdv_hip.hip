@@ -37,7 +37,7 @@ constexpr int kStatWords = 16;          // 128-byte slot per wave
 // is a multiple of 65,536 envs up to 3 M — an empirical rule (tools/xcd_map_ab.py, profiles/r02_xcd_order_ab.txt; order toggled per
 // launch on one allocation): -10 % at 524,288 envs (42.2 -> 37.8 us), -9 % at 786,432, -7 % at 262,144, -5 % at 1 M, -3 % at 196,608
 // and 2 M, -1 % at 3 M; +2 % at 4 M, +3.5 % at 8 M; and off those sizes it does not pay: +8 % at 1,000,000, +6 % at 262,400, -4 % at
-// 528,384, 0 at 500,000.  Padding or skewing the arrays instead changes nothing (chunk_stride).  RDV_XCD_ORDER=0|1 in the
+// 528,384, 0 at 500,000.  Padding or skewing the arrays instead recovers less (chunk_stride).  RDV_XCD_ORDER=0|1 in the
 // environment at rdv_create forces it off / on (diagnostics).
 constexpr int64_t kXcdOrderMaxEnvs = 3145728;
 static inline bool xcd_order_by_size(int64_t n) { return n <= kXcdOrderMaxEnvs && n % 65536 == 0; }
@@ -755,8 +755,8 @@ static inline int64_t align_up(int64_t x, int64_t a) { return (x + a - 1) / a * 
 static inline int64_t n_waves(int64_t n) { return (n + kBlock - 1) / kBlock * (kBlock / kWave); }
 // Chunk stride (in envs): chunk c of env i is vector c * stride + i of the workspace.  The seven chunk arrays are walked in
 // lockstep, and every BASELINE size puts them a power of two apart; padding each array to 64 KiB / 2 MiB and offsetting neighbours by
-// 4 ... 260 KiB was measured and changes nothing at any size (tools/chunk_skew_sweep.py, profiles/r02_chunk_skew.txt), so the arrays
-// lie back to back.  RDV_CHUNK_ALIGN / RDV_CHUNK_SKEW (bytes, multiples of 256) in the environment set a padded spacing for that tool.
+// 4 ... 260 KiB was measured (tools/chunk_skew_sweep.py, profiles/r02_chunk_skew.txt): 3-5 % at 0.5-1 M envs under the plain block
+// order, nothing on top of the XCD-contiguous order (xcd_order_by_size), which gains more — so the arrays lie back to back.  RDV_CHUNK_ALIGN / RDV_CHUNK_SKEW (bytes, multiples of 256) in the environment set a padded spacing for that tool.
 static inline int64_t chunk_stride(int64_t n, int storage) {
   static const int64_t align = [] { const char* x = getenv("RDV_CHUNK_ALIGN"); const long long v = x ? atoll(x) : 0; return (int64_t)(v >= 256 && v % 256 == 0 ? v : 0); }();
   static const int64_t skew = [] { const char* x = getenv("RDV_CHUNK_SKEW"); const long long v = x ? atoll(x) : 0; return (int64_t)(v >= 0 && v % 256 == 0 ? v : 0); }();
