@@ -283,6 +283,30 @@ def main():
         torch.cuda.synchronize()
         return sorted(ev[r_].elapsed_time(ev[r_ + 1]) for r_ in range(reps))[reps // 2] * 1e3 / steps
 
+    # ---- informational: the SB3-facing NumPy boundary (actions H2D, obs/reward/done D2H, infos) — PCIe-inclusive, never the bench value.
+    # (Runs before the large legs below: after they have churned the allocators the same loop measures 1.7-1.9 ms per step instead of 1.3.)
+    if rank == 0 and world == 1 and not args.no_policy:
+        from reinforcement_learning_rendezvous_amd.vec_env import RendezvousVecEnv
+        vec = RendezvousVecEnv(n, engine=env)
+        a_np = [r_.cpu().numpy() for r_ in ring[:4]]
+        vec.reset()
+        for k_ in range(10):
+            vec.step(a_np[k_ % 4])
+        per = []
+        for k_ in range(200):
+            p0 = time.perf_counter()
+            vec.step(a_np[k_ % 4])
+            per.append(time.perf_counter() - p0)
+        per.sort()
+        out["vecenv_numpy_boundary"] = {"value": n * len(per) / sum(per), "unit": "env steps/s", "steps": len(per),
+                                        "median_value": n / per[len(per) // 2],
+                                        "ms_per_step": {"mean": sum(per) / len(per) * 1e3, "median": per[len(per) // 2] * 1e3,
+                                                        "p90": per[int(len(per) * 0.9)] * 1e3, "max": per[-1] * 1e3},
+                                        "note": "RendezvousVecEnv.step with NumPy actions in, NumPy obs/reward/done + infos out (PCIe-inclusive; "
+                                                "never the bench value): one packed D2H message + the rows of the finished envs; ~70 % of it "
+                                                "is building the infos dicts of the ~3,500 finished envs per step (profiles/r02_vecenv_profile.txt)"}
+        env.reset()
+
     # ---- the same metric with fp64 state storage (parity mode), N=1 only
     if rank == 0 and world == 1 and args.storage == "f32":
         try:
@@ -419,24 +443,6 @@ def main():
             out["policy_rollout"]["hip_rollout_kernel_error"] = repr(exc)
         out["policy_rollout"]["value"] = max(v for k_, v in out["policy_rollout"].items() if isinstance(v, float))
         pol.close()
-        # the SB3-facing NumPy boundary (actions H2D, obs/reward/done D2H, infos) — PCIe-inclusive, never the bench value
-        from reinforcement_learning_rendezvous_amd.vec_env import RendezvousVecEnv
-        vec = RendezvousVecEnv(n, engine=env)
-        a_np = ring[0].cpu().numpy()
-        vec.reset()
-        for _ in range(5):
-            vec.step(a_np)
-        per = []
-        for _ in range(60):
-            p0 = time.perf_counter()
-            vec.step(a_np)
-            per.append(time.perf_counter() - p0)
-        per.sort()
-        out["vecenv_numpy_boundary"] = {"value": n * len(per) / sum(per), "unit": "env steps/s", "steps": len(per),
-                                        "median_value": n / per[len(per) // 2], "ms_per_step": {"mean": sum(per) / len(per) * 1e3, "median": per[len(per) // 2] * 1e3,
-                                                                                                 "max": per[-1] * 1e3},
-                                        "note": "RendezvousVecEnv.step with NumPy actions in, NumPy obs/reward/done + infos out (PCIe-inclusive; "
-                                                "never the bench value): one packed D2H message + the rows of the finished envs"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, args.cpu_seconds)

@@ -74,3 +74,18 @@ print(f"phase breakdown (ms per step, {K} steps, ~{idx.size} finished envs per s
 for nm, v in zip(names, acc / K * 1e3):
     print(f"   {nm:32s} {v:6.3f}")
 print(f"   {'sum':32s} {acc.sum() / K * 1e3:6.3f}")
+
+# ---- rare slow steps: 400 steps, the slowest ones and where they fall (collector on, then off)
+for label, off in (("collector on", False), ("collector off", True)):
+    if off:
+        gc.disable()
+    per = []
+    for k in range(400):
+        t0 = time.perf_counter()
+        vec.step(acts[k % 8])
+        per.append(time.perf_counter() - t0)
+    gc.enable()
+    per_ms = np.array(per) * 1e3
+    worst = np.argsort(per_ms)[::-1][:6]
+    print(f"{label}: mean {per_ms.mean():.3f} ms, median {np.median(per_ms):.3f}, p90 {np.percentile(per_ms, 90):.3f}, p99 {np.percentile(per_ms, 99):.3f}; "
+          f"slowest: " + ", ".join(f"step {int(w)}: {per_ms[w]:.1f} ms" for w in worst))
