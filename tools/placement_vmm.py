@@ -70,9 +70,7 @@ def run(label, block=None, order=0):
     print(f"{label:78s}: {best:7.1f} us per launch, {293 * n / (best * 1e-6) / 8e12:.3f} of 8 TB/s, episodes {st['episodes']}", flush=True)
 
 
-for rep in range(2):
+GiB = 1024 * MiB
+for rep in range(8):
     run("plain allocation (torch caching allocator -> hipMalloc)")
-for block in (2 * MiB, 16 * MiB, 64 * MiB, 256 * MiB):
-    for order, nm in ((0, "in creation order"), (1, "reversed"), (2, "shuffled"), (3, "even blocks, then odd")):
-        run(f"workspace from {block // MiB:3d} MiB blocks, mapped {nm}", block, order)
-run("plain allocation (again)")
+    run("workspace as ONE block", 4 * GiB, 0)
