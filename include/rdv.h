@@ -226,7 +226,7 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out_host, voi
 /* n_steps calls of rdv_step for an OPEN-LOOP action tape actions [n_steps,N,6] in ONE persistent launch: the env state stays in
  * registers between the steps and there is no launch boundary (~4 us per step at 65,536 envs instead of ~7.8).  out->obs
  * [n_steps,N,17], out->reward [n_steps,N], out->done [n_steps,N] and (nullable) out->done_reason [n_steps,N] are written; the
- * other members of RdvStepOut must be NULL.  N must be a multiple of 4.  Same results, final state and statistics as the loop,
+ * other members of RdvStepOut must be NULL.  Same results, final state and statistics as the loop,
  * general rigid bodies (rdv_set_rigid_body) included. */
 int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const RdvStepOut* out_host, void* stream);
 

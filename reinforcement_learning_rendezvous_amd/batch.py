@@ -151,7 +151,7 @@ class RendezvousBatch:
     def step_many(self, actions, out=None):
         """``step`` for every row of an OPEN-LOOP action tape ``actions`` [K,N,6] in ONE kernel launch (state in registers, no
         launch boundaries).  Returns a dict ``obs`` [K,N,17], ``reward`` [K,N], ``done`` [K,N] (uint8), ``done_reason`` [K,N];
-        pass it back as ``out`` to reuse the buffers.  Same results as calling ``step`` K times."""
+        pass it back as ``out`` to reuse the buffers.  Same results as calling ``step`` K times; any N."""
         K, n, dev = int(actions.shape[0]), self.num_envs, self.device
         self._check_tensor(actions, (K, n, N.ACT_DIM), torch.float32, "actions")
         if out is None or out["obs"].shape[0] != K:

@@ -171,10 +171,12 @@ __device__ __forceinline__ void load_actions(const float* __restrict__ actions, 
 }
 
 // observations [64,17] of one wave: staged rows in LDS -> contiguous 16-byte-per-lane global stores
-__device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t wave_base, int64_t rows, int lane, const float* wl) {
+// (`aligned`: dst is 16-byte aligned — always for [N,17] rows of a 64-env wave, for row t of a [T,N,17] tape only if N % 4 == 0)
+__device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t wave_base, int64_t rows, int lane, const float* wl,
+                                               bool aligned = true) {
   if (rows <= 0) return;
   float* dst = obs + wave_base * RDV_OBS_DIM;
-  if (rows == kWave) {
+  if (rows == kWave && aligned) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int q = k * kWave + lane;
@@ -1427,7 +1429,6 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: call rdv_reset first (state is undefined until reset(), as in the reference)");
   if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions and obs must be 16-byte aligned");
-  if ((h->n & 3) != 0) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: n_envs must be a multiple of 4 (rows of [K,N,17] / [K,N,6] start 16-byte aligned)");
   DeviceGuard guard(h->device);
   h->raw_state = false;   // the kernel integrates injected (unnormalised) quaternions itself
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
   const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
   const int K = A.n_steps;
   const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform: the barriers below are executed by all waves or by none
+  const bool vec_rows = (n & 3) == 0;                   // rows of [K,N,17] start 16-byte aligned
   V* ws = reinterpret_cast<V*>(A.ws);
 
   if (env_role) {
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
 #pragma unroll
       for (int j = 0; j < RDV_OBS_DIM; ++j) my_obs[lane * RDV_OBS_DIM + j] = r.obs[j];
       wave_lds_fence();
-      store_obs_rows(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs);
+      store_obs_rows(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs, vec_rows);
       wave_lds_fence();   // the rows are rewritten by the next step
     }
     if (active) store_env<ST>(ws, A.cs, i, e, wt_dirty);

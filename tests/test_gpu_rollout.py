@@ -133,7 +133,7 @@ def test_rollout_argument_checks():
 
 
 @pytest.mark.parametrize("n,storage,on_done", [(1000, "f32", "reset"), (260, "f64", "reset"), (4096, "f32", "halt"),
-                                               (512, "f32", "continue")])
+                                               (512, "f32", "continue"), (777, "f32", "reset"), (66, "f64", "reset")])   # n % 4 != 0: scalar row stores
 def test_step_many_equals_the_step_by_step_loop(n, storage, on_done):
     """rdv_step_many (K steps of an open-loop action tape in one persistent launch) against K calls of rdv_step."""
     from helpers import counter_actions
@@ -145,7 +145,7 @@ def test_step_many_equals_the_step_by_step_loop(n, storage, on_done):
     out = many.step_many(tape)
     n_done = 0
     for t in range(K):
-        o, r, d = loop.step(tape[t])
+        o, r, d = loop.step(tape[t].clone())      # (a row of the tape is 16-byte aligned only if n % 4 == 0)
         assert torch.equal(out["obs"][t], o), f"obs, step {t}"
         assert torch.equal(out["reward"][t], r), f"reward, step {t}"
         assert torch.equal(out["done"][t], d), f"done, step {t}"
@@ -158,9 +158,9 @@ def test_step_many_equals_the_step_by_step_loop(n, storage, on_done):
     # a second tape continues from there, and single steps can follow a tape
     out2 = many.step_many(tape[:8], out=None)
     for t in range(8):
-        o, r, d = loop.step(tape[t])
+        o, r, d = loop.step(tape[t].clone())      # (a row of the tape is 16-byte aligned only if n % 4 == 0)
         assert torch.equal(out2["obs"][t], o) and torch.equal(out2["done"][t], d)
-    o1, _, _ = many.step(tape[9]); o2, _, _ = loop.step(tape[9])
+    o1, _, _ = many.step(tape[9].clone()); o2, _, _ = loop.step(tape[9].clone())
     assert torch.equal(o1, o2) and torch.equal(many.get_state(), loop.get_state())
     many.close(); loop.close()
 
@@ -175,8 +175,3 @@ def test_step_many_argument_checks():
     with pytest.raises(ValueError):
         env.step_many(torch.zeros((4, 63, 6), device="cuda:0"))
     env.close()
-    odd = _batch(66)
-    odd.reset()
-    with pytest.raises(RdvError, match="multiple of 4"):
-        odd.step_many(torch.zeros((2, 66, 6), device="cuda:0"))
-    odd.close()
