@@ -1369,8 +1369,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   if (!actions || !out || !out->obs || !out->reward || !out->done)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: actions, obs, reward and done are required");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: call rdv_reset first (state is undefined until reset(), as in the reference)");
-  if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
-    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: actions and obs must be 16-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(actions) & 7) || (reinterpret_cast<uintptr_t>(out->obs) & 15))   // 8-byte loads of action rows, 16-byte stores of observation rows
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: actions must be 8-byte aligned (any row of a [K,N,6] tape is) and obs 16-byte aligned");
   if (out->diag && (reinterpret_cast<uintptr_t>(out->diag) & 7)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: diag must be 8-byte aligned");
   DeviceGuard guard(h->device);
   StepArgs A;
@@ -1427,8 +1427,8 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if (out->terminal_obs || out->episode_return || out->episode_length || out->diag || out->eval)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: terminal_obs, episode_return, episode_length, diag and eval are outputs of rdv_step only");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: call rdv_reset first (state is undefined until reset(), as in the reference)");
-  if ((reinterpret_cast<uintptr_t>(actions) & 15) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
-    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions and obs must be 16-byte aligned");
+  if ((reinterpret_cast<uintptr_t>(actions) & 7) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
+    return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions must be 8-byte aligned and obs 16-byte aligned");
   DeviceGuard guard(h->device);
   h->raw_state = false;   // the kernel integrates injected (unnormalised) quaternions itself
   hipStream_t s = static_cast<hipStream_t>(stream);

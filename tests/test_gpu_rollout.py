@@ -145,7 +145,7 @@ def test_step_many_equals_the_step_by_step_loop(n, storage, on_done):
     out = many.step_many(tape)
     n_done = 0
     for t in range(K):
-        o, r, d = loop.step(tape[t].clone())      # (a row of the tape is 16-byte aligned only if n % 4 == 0)
+        o, r, d = loop.step(tape[t])                # (rdv_step reads action rows with 8-byte loads: any row of a tape will do)
         assert torch.equal(out["obs"][t], o), f"obs, step {t}"
         assert torch.equal(out["reward"][t], r), f"reward, step {t}"
         assert torch.equal(out["done"][t], d), f"done, step {t}"
@@ -158,9 +158,9 @@ def test_step_many_equals_the_step_by_step_loop(n, storage, on_done):
     # a second tape continues from there, and single steps can follow a tape
     out2 = many.step_many(tape[:8], out=None)
     for t in range(8):
-        o, r, d = loop.step(tape[t].clone())      # (a row of the tape is 16-byte aligned only if n % 4 == 0)
+        o, r, d = loop.step(tape[t])                # (rdv_step reads action rows with 8-byte loads: any row of a tape will do)
         assert torch.equal(out2["obs"][t], o) and torch.equal(out2["done"][t], d)
-    o1, _, _ = many.step(tape[9].clone()); o2, _, _ = loop.step(tape[9].clone())
+    o1, _, _ = many.step(tape[9]); o2, _, _ = loop.step(tape[9])
     assert torch.equal(o1, o2) and torch.equal(many.get_state(), loop.get_state())
     many.close(); loop.close()
 
