@@ -220,7 +220,8 @@ int rdv_get_rigid_body(rdv_handle h, RdvRigidBody* out_host);
 /* RendezvousEnv.reset() (:223-270) for every env, or for envs with mask[i] != 0.  obs_out [N,17] nullable. */
 int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream);
 
-/* RendezvousEnv.step() (:160-221) for every env: ONE kernel launch.  actions [N,6] f32 (not clipped, as :170). */
+/* RendezvousEnv.step() (:160-221) for every env: ONE kernel launch.  actions [N,6] f32 (not clipped, as :170), 8-byte aligned
+ * (any row of a [K,N,6] tape is); out->obs 16-byte aligned. */
 int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out_host, void* stream);
 
 /* n_steps calls of rdv_step for an OPEN-LOOP action tape actions [n_steps,N,6] in ONE persistent launch: the env state stays in
