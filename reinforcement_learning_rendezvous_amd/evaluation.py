@@ -90,57 +90,50 @@ def env_attributes(params):
 
 @torch.no_grad()
 def record_trajectories(policy, env, initial_states=None, deterministic=True, generator=None):
-    """save_new_trajectory.evaluate (:37-204) for every env of ``env`` (halt mode); returns one record dict per env."""
+    """save_new_trajectory.evaluate (:37-204) for every env of ``env`` (halt mode); returns one record dict per env.
+
+    The step loop keeps the histories (state, evaluator diagnostics, action, reward, done per step) in device tensors and runs for
+    the number of steps after which every episode has ended (halted envs are left untouched); they cross to the host once, after the
+    loop, where the per-env records are cut to their episode lengths."""
     p = env.params
     m = env.num_envs
-    steps_max = int(p.t_max / p.dt) + 1                                  # :68
+    K = episode_steps_bound(p)                                           # :68 sizes its arrays int(t_max / dt) + 1 >= K
     env.reset()                                                          # :46
     if initial_states is not None:
         env.set_state(torch.as_tensor(np.asarray(initial_states, dtype=np.float64)))
     obs = env.observe()                                                  # :60
-    st = np.full((m, 20, steps_max + 1), np.nan)
-    act = np.full((m, 6, steps_max + 1), np.nan)
-    rew = np.full((m, 1, steps_max + 1), np.nan)
-    err = np.full((m, 4, steps_max + 1), np.nan)
-    tt = np.full((m, 1, steps_max + 1), np.nan)
-    d = env.diagnose().cpu().numpy()
-    st[:, :, 0] = env.get_state().cpu().numpy()                          # :87-92
-    err[:, :, 0] = d[:, 0:4]                                             # :93
-    collisions = d[:, 4].copy()                                          # :94
-    successes = d[:, 5].copy()                                           # :95
-    d_koz = d[:, 6].copy()                                               # :96
-    tt[:, 0, 0] = 0.0                                                    # :97
-    length = np.zeros(m, dtype=np.int64)
-    active = np.ones(m, dtype=bool)
-    k = 1
-    while active.any():                                                  # :103
-        if k > steps_max + 1:
-            raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
+    dev = obs.device
+    S = torch.empty((K + 1, m, 20), dtype=torch.float64, device=dev)
+    D = torch.empty((K + 1, m, 8), dtype=torch.float64, device=dev)
+    A = torch.empty((K, m, 6), dtype=torch.float32, device=dev)
+    R = torch.empty((K, m), dtype=torch.float32, device=dev)
+    DN = torch.empty((K, m), dtype=torch.uint8, device=dev)
+    S[0] = env.get_state()                                               # :87-92
+    D[0] = env.diagnose()                                                # :93-96
+    for k in range(1, K + 1):                                            # :103 `while not done`, for all envs at once
         a = policy.act(obs, deterministic=deterministic, generator=generator).contiguous()      # :110-115
         obs, r, done = env.step(a, diag=True)                                                    # :124
-        dg = env.diag.cpu().numpy()
-        s_now = env.get_state().cpu().numpy()
-        a_np, r_np, dn = a.cpu().numpy(), r.cpu().numpy(), done.cpu().numpy().astype(bool)
-        if k <= steps_max:
-            st[active, :, k] = s_now[active]                                                     # :129-134
-            act[active, :, k - 1] = a_np[active]                                                 # :139
-            rew[active, 0, k] = r_np[active]                                                     # :140
-            err[active, :, k] = dg[active, 0:4]                                                  # :141
-            tt[active, 0, k] = round(k * p.dt, 3)                                                # :146
-        collisions[active] += dg[active, 4]                                                      # :142
-        d_koz[active] = np.minimum(d_koz[active], dg[active, 6])                                 # :143
-        successes[active] += dg[active, 5]                                                       # :144-145
-        length[active] = k
-        active &= ~dn
-        k += 1
+        S[k] = env.get_state(); D[k] = env.diag; A[k - 1] = a; R[k - 1] = r; DN[k - 1] = done
+    st_h, dg_h, a_h, r_h = S.cpu().numpy(), D.cpu().numpy(), A.cpu().numpy().astype(np.float64), R.cpu().numpy().astype(np.float64)
+    dn_h = DN.cpu().numpy().astype(bool)
+    if not dn_h[K - 1].all():
+        raise RuntimeError("an episode outlived t_max; the time-limit termination is broken")
+    length = dn_h.argmax(axis=0) + 1                                     # steps of each episode: the first step that reported done
+    live = np.arange(1, K + 1)[:, None] <= length[None, :]               # [K, m]: step k belongs to env i's episode
+    collisions = dg_h[0, :, 4] + np.where(live, dg_h[1:, :, 4], 0.0).sum(axis=0)                 # :94, :142
+    successes = dg_h[0, :, 5] + np.where(live, dg_h[1:, :, 5], 0.0).sum(axis=0)                  # :95, :144-145
+    d_koz = np.minimum(dg_h[0, :, 6], np.where(live, dg_h[1:, :, 6], np.inf).min(axis=0))        # :96, :143
     attrs = env_attributes(p)
     records = []
     for i in range(m):
-        L = length[i] + 1                                                # :160-170 (nan columns dropped)
-        s = st[i, :, :L]
+        L = int(length[i])                                               # :160-170 (nan columns dropped): columns 0..L
+        s = st_h[:L + 1, i, :].T
+        act = np.full((6, L + 1), np.nan); act[:, :L] = a_h[:L, i, :].T                          # :139: a[k-1] is the action of step k
+        rew = np.full((1, L + 1), np.nan); rew[0, 1:] = r_h[:L, i]                               # :140
+        tt = np.round(np.arange(L + 1) * p.dt, 3)[None, :]                                       # :97, :146
         rec = dict(attrs)
-        rec.update(rc=s[0:3], vc=s[3:6], qc=s[6:10], wc=s[10:13], qt=s[13:17], wt=s[17:20], a=act[i, :, :L],
-                   rew=rew[i, :, :L], errors=err[i, :, :L], t=tt[i, :, :L], d_koz=float(d_koz[i]),
+        rec.update(rc=s[0:3], vc=s[3:6], qc=s[6:10], wc=s[10:13], qt=s[13:17], wt=s[17:20], a=act,
+                   rew=rew, errors=dg_h[:L + 1, i, 0:4].T, t=tt, d_koz=float(d_koz[i]),
                    collisions=int(collisions[i]), successes=int(successes[i]), process_action=None)    # :176-182
         records.append(rec)
     return records
