@@ -185,7 +185,9 @@ int rdv_seed(rdv_handle h, uint64_t seed);
  */
 int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth);
 
-/* Tuning: force a kernel variant (RdvKernelVariant).  Results do not depend on it. */
+/* Tuning: force a kernel variant (RdvKernelVariant).  Results do not depend on it.  (Diagnostics only, read from the environment
+ * at rdv_create: RDV_XCD_ORDER=0|1 forces the fused kernels' workgroup order — plain, or each XCD walking a contiguous eighth of
+ * the batch, which is otherwise chosen by size; RDV_CHUNK_ALIGN / RDV_CHUNK_SKEW pad the state arrays of the workspace.) */
 int rdv_set_kernel_variant(rdv_handle h, int variant);
 
 /*
