@@ -275,7 +275,9 @@ def main():
             for t in range(steps):
                 e.step(acts[t % len(acts)])
         torch.cuda.synchronize()
-        g.replay(); torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        while time.perf_counter() - w0 < 0.1:      # sustained load before timing: the shader clock takes ~20 ms of load to settle
+            g.replay(); torch.cuda.synchronize()
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
         ev[0].record()
         for r_ in range(reps):
@@ -346,7 +348,8 @@ def main():
                                            "traffic": tr["bytes_per_launch"] if tr else None,
                                            "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" if tr else None},
                               "note": "1.2 GB of state + I/O per launch: HBM, not Infinity Cache; value = the median of three fresh allocations "
-                                      "of the batch (launch_us_per_allocation: physical placement moves it by up to 20 %)"}
+                                      "of the batch, each after 0.1 s of sustained load (launch_us_per_allocation: it has two modes, by box and moment, most plausibly "
+                                      "the clocks the socket sustains at its power limit: DESIGN.md section 5)"}
             del acts_b
             torch.cuda.empty_cache()
         except Exception as exc:  # pragma: no cover
@@ -359,11 +362,11 @@ def main():
             tape = torch.stack([ring[t % RING] for t in range(k_many)]).contiguous()
             env.reset()
             bufs = env.step_many(tape)
-            for _ in range(3):
-                env.step_many(tape, out=bufs)
-            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            while time.perf_counter() - w0 < 0.1:      # sustained load before timing (see timed_steps)
+                env.step_many(tape, out=bufs); torch.cuda.synchronize()
             m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 32
+            reps = 128
             m0.record()
             for _ in range(reps):
                 env.step_many(tape, out=bufs)
@@ -386,6 +389,25 @@ def main():
         k2 = 256
         act_buf = torch.empty((n, 6), dtype=torch.float32, device=device)
 
+        def sustained(run, warm_s=0.15, timed_s=0.25):
+            """calls of `run` per second under sustained load: the shader clock needs tens of ms of load to settle (the first 20 ms of
+            rdv_rollout launches after an idle moment run 11 % slower than the rest, tools/sustained_rollout.py), so every leg first
+            runs for `warm_s`, then is timed over at least `timed_s`"""
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            while time.perf_counter() - p0 < warm_s:
+                run()
+                torch.cuda.synchronize()
+            calls, p0 = 0, time.perf_counter()
+            while True:
+                for _ in range(4):
+                    run()
+                calls += 4
+                torch.cuda.synchronize()
+                dt_ = time.perf_counter() - p0
+                if dt_ >= timed_s:
+                    return calls / dt_
+
         def rollout_rate(backend, graph):
             """env steps/s of [policy forward + Gaussian sample + clip] -> [env step], eager or replayed from a HIP graph"""
             pol.backend = backend
@@ -405,14 +427,10 @@ def main():
                 run = lambda: [g.replay() for _ in range(k2 // 16)]
             else:
                 run = lambda: [step() for _ in range(k2)]
-            torch.cuda.synchronize()
-            p0 = time.perf_counter()
-            run()
-            torch.cuda.synchronize()
             del obs
-            return n * k2 / (time.perf_counter() - p0)
+            return n * k2 * sustained(run)
 
-        out["policy_rollout"] = {"unit": "env steps/s", "steps": k2,
+        out["policy_rollout"] = {"unit": "env steps/s", "steps": k2, "timing": "every leg: 0.15 s of its own workload untimed, then >= 0.25 s timed",
                                  "timing_only": "the *_graph legs replay a captured graph whose actor launches carry the noise counter of the "
                                                 "capture: timing is that of a rollout, the sampled actions repeat every 16 steps "
                                                 "(hip_rollout_kernel and the *_eager legs advance the counter)",
@@ -431,12 +449,7 @@ def main():
             bufs = env.rollout(pol, t_roll)
             for _ in range(2):
                 env.rollout(pol, t_roll, out=bufs)
-            torch.cuda.synchronize()
-            p0 = time.perf_counter()
-            for _ in range(k2 // t_roll * 4):
-                env.rollout(pol, t_roll, out=bufs)
-            torch.cuda.synchronize()
-            out["policy_rollout"]["hip_rollout_kernel"] = n * (k2 // t_roll * 4) * t_roll / (time.perf_counter() - p0)
+            out["policy_rollout"]["hip_rollout_kernel"] = n * t_roll * sustained(lambda: env.rollout(pol, t_roll, out=bufs))
             out["policy_rollout"]["hip_rollout_kernel_steps_per_launch"] = t_roll
             del bufs
         except Exception as exc:  # pragma: no cover - depends on the runtime

@@ -1133,6 +1133,9 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   A.prep = h->prep; A.prep_tag = h->prep_tag;
   A.env_id_offset = h->env_id_offset; A.noise_seed = noise_seed; A.noise_counter0 = noise_counter0;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps; A.deterministic = deterministic ? 1 : 0;
+#ifdef RDV_STAMPS
+  A.stamps = h->stamps;
+#endif
   const dim3 grid((unsigned)((h->n + kRollEnvs - 1) / kRollEnvs)), block(kRollBlock);
   const bool f32 = h->storage == RDV_STORAGE_F32;
   if (h->general) {

@@ -173,19 +173,20 @@ __device__ __forceinline__ void actor_means(const float* w, const float* rows, i
   mean[0] = d3[0][0]; mean[1] = d3[0][1]; mean[2] = d3[0][2]; mean[3] = d3[0][3];   // rows (e & 3) + 4 h
 }
 
-// mean -> sample (SB3 rollout form: mean + exp(log_std) N(0,1)) for this lane's components; returns the ENV's Gaussian log-density
-// log N(a; mean, std) summed over the 6 components (both lanes of an env get it).  Noise: Philox4x32-10 keyed by (seed, global env
-// id, counter); block 0 gives the normals of components 0..3, block 1 those of 4, 5 — a lane draws only its own half's block.
-__device__ __forceinline__ float actor_sample(const float* w, int lane, int deterministic, uint64_t seed, uint64_t id, uint64_t counter,
-                                              float (&a)[4]) {
+// Exploration noise of this lane's action components: Philox4x32-10 keyed by (seed, global env id, counter); block 0 gives the normals
+// of components 0..3 (lower lane half), block 1 those of 4, 5 (upper half) — a lane draws only its own half's block.
+__device__ __forceinline__ void actor_noise(int lane, uint64_t seed, uint64_t id, uint64_t counter, float (&z)[4]) {
   const int h = lane >> 5;
-  float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-  if (!deterministic) {
-    uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32), c2 = (uint32_t)counter, c3 = (uint32_t)(counter >> 32) * 2u + (uint32_t)h;
-    philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x504F4C49u);   // key tweak: not the reset stream
-    box_muller(c0, c1, z[0], z[1]);
-    box_muller(c2, c3, z[2], z[3]);
-  }
+  uint32_t c0 = (uint32_t)id, c1 = (uint32_t)(id >> 32), c2 = (uint32_t)counter, c3 = (uint32_t)(counter >> 32) * 2u + (uint32_t)h;
+  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32) ^ 0x504F4C49u);   // key tweak: not the reset stream
+  box_muller(c0, c1, z[0], z[1]);
+  box_muller(c2, c3, z[2], z[3]);
+}
+
+// mean -> sample (SB3 rollout form: mean + exp(log_std) z, z ~ N(0,1) from actor_noise; z = 0 when deterministic) for this lane's
+// components; returns the ENV's Gaussian log-density log N(a; mean, std) summed over the 6 components (both lanes of an env get it).
+__device__ __forceinline__ float actor_apply(const float* w, int lane, const float (&z)[4], float (&a)[4]) {
+  const int h = lane >> 5;
   float lp = 0.0f;
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
@@ -194,6 +195,12 @@ __device__ __forceinline__ float actor_sample(const float* w, int lane, int dete
     lp += valid ? fmaf(-0.5f * z[c], z[c], -w[kPolLogStd + 4 * h + c]) : 0.0f;
   }
   return (lp + __shfl_xor(lp, 32)) - 5.5136312f;          // - 6/2 log(2 pi)
+}
+__device__ __forceinline__ float actor_sample(const float* w, int lane, int deterministic, uint64_t seed, uint64_t id, uint64_t counter,
+                                              float (&a)[4]) {
+  float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  if (!deterministic) actor_noise(lane, seed, id, counter, z);
+  return actor_apply(w, lane, z, a);
 }
 
 __device__ __forceinline__ float clip_action(float v) { return (v != v) ? v : fminf(fmaxf(v, -1.0f), 1.0f); }   // np.clip (NaN stays NaN)

@@ -68,9 +68,17 @@ struct RolloutArgs {
   int32_t on_done;
   int32_t n_steps;
   int32_t deterministic;
+#ifdef RDV_STAMPS
+  unsigned long long* stamps;   // diagnostic build (tools/rollout_stamps.py): [waves][8] cycle sums over the launch's steps
+#endif
 };
 
 // kGeneral: general rigid bodies (rdv_set_rigid_body) — both attitudes by the reference's RK45 scheme per lane, as in step_kernel.
+#ifdef RDV_STAMPS
+#define ROLL_T(var) __builtin_amdgcn_sched_barrier(0); const unsigned long long var = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0)
+#else
+#define ROLL_T(var)
+#endif
 template <typename ST, bool kGeneral = false>
 __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __restrict__ Pp, const float* __restrict__ W,
                                                              const RolloutArgs A) {
@@ -83,6 +91,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   uint64_t* stat_lds = reinterpret_cast<uint64_t*>(act_cur + kRollEnvs * RDV_ACT_DIM);   // [4][16]: the rollout's statistics per env wave
   uint32_t* job_kind = reinterpret_cast<uint32_t*>(stat_lds + kRollEnvWaves * kStatWords);   // [256]
   uint32_t* job_counter = job_kind + kRollEnvs;                                              // [256]
+  uint32_t* refills_done = reinterpret_cast<uint32_t*>(stat_lds + (kStatWords - 1));         // word 15 of env wave 0's slot (12 are used; zeroed below)
   V* slot_chunks = reinterpret_cast<V*>(job_counter + kRollEnvs);                            // [7][256]
   float4* slot_obs = reinterpret_cast<float4*>(slot_chunks + kChunks * kRollEnvs);           // [5][256]
   const SlotStore<ST> L = lds_slot_store<ST>(slot_chunks, slot_obs, kRollEnvs);              // the workgroup's slots
@@ -151,7 +160,27 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   if (!env_role) {
    const bool refills = resets && a_wave < kGroupWaves;
    uint16_t* list = lists + (a_wave & (kGroupWaves - 1)) * kRollEnvs;
+   // The exploration noise of step t does not depend on the observation: it is drawn while the env waves run step t-1 (these waves
+   // only wait then) and parked in the wave's staging rows, which hold the unclipped actions only between sampling and their store.
+   auto draw_noise = [&](int t_next, int ln_) {
+     if (A.deterministic || a_rows <= 0) return;
+     const int er_ = ln_ & 31, eh_ = ln_ >> 5;
+     float z[4];
+     actor_noise(ln_, A.noise_seed, A.env_id_offset + (uint64_t)(a_env0 + er_), A.noise_counter0 + (uint64_t)t_next, z);
+     if (eh_ == 0) {
+#pragma unroll
+       for (int c = 0; c < 4; ++c) araw[er_ * RDV_ACT_DIM + c] = z[c];
+     } else {
+       araw[er_ * RDV_ACT_DIM + 4] = z[0]; araw[er_ * RDV_ACT_DIM + 5] = z[1];
+     }
+     wave_fence();
+   };
+   draw_noise(0, lane);
+#ifdef RDV_STAMPS
+   unsigned long long acc_a = 0, acc_r = 0, acc_w1 = 0, acc_w2 = 0;
+#endif
    for (int t = 0; t < T; ++t) {
+    ROLL_T(ta0);
     // the lane id is re-derived every step from an opaque copy: the per-lane addresses of this loop (row stores, LDS fragments,
     // the refill's job arrays) are then recomputed where they are used (a few integer operations) instead of being hoisted out of the
     // loop, where they sat in ~40 registers for the whole rollout and spilled to scratch at the 168-VGPR budget of three waves per SIMD
@@ -179,8 +208,16 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       const int er = ln & 31, eh = ln >> 5;
       float a[4];
       actor_means(w, xin, ln, a);
-      const float logp = actor_sample(w, ln, A.deterministic, A.noise_seed, A.env_id_offset + (uint64_t)(a_env0 + er),
-                                      A.noise_counter0 + (uint64_t)t, a);
+      float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (!A.deterministic) {
+        if (eh == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) z[c] = araw[er * RDV_ACT_DIM + c];
+        } else {
+          z[0] = araw[er * RDV_ACT_DIM + 4]; z[1] = araw[er * RDV_ACT_DIM + 5];
+        }
+      }
+      const float logp = actor_apply(w, ln, z, a);
       // unclipped actions -> staging rows -> HBM; clipped actions -> LDS for the env waves
       if (eh == 0) {
 #pragma unroll
@@ -212,18 +249,45 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       }
       wave_fence();   // the staging rows are free again before the next step writes them
     }
-    // actor waves 0-3 (one per SIMD): this wave's part of the slots that were taken in step t-1 (or arrived marked)
-    if (refills) refill_pass_lds<ST>(a_wave, ln, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
-    __syncthreads();   // actions of step t are in LDS; every listed slot has been refilled
+    ROLL_T(ta1);
+    __syncthreads();   // actions of step t are in LDS
+    ROLL_T(ta2);
+    // Beside the env phase (these waves would only wait): actor waves 0-3 (one per SIMD) refill their part of the slots that were
+    // taken in step t-1 (or arrived marked), then say so — the env waves look at that counter before they take a slot or rewrite the
+    // job arrays; and every actor wave draws its noise for step t+1.
+    if (refills) {
+      refill_pass_lds<ST>(a_wave, ln, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
+      if (ln == 0) __hip_atomic_fetch_add(refills_done, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (t + 1 < T) draw_noise(t + 1, ln);
+    ROLL_T(ta3);
     __syncthreads();   // observations of step t+1 are in LDS
+    ROLL_T(ta4);
+#ifdef RDV_STAMPS
+    acc_a += ta1 - ta0; acc_r += ta2 - ta1; acc_w1 += ta3 - ta2; acc_w2 += ta4 - ta3;
+#endif
    }
+#ifdef RDV_STAMPS
+   if (A.stamps && lane == 0) {
+     unsigned long long* o = A.stamps + ((uint64_t)blockIdx.x * 12 + wv) * 8;
+     o[0] = acc_a; o[1] = acc_r; o[2] = acc_w1; o[3] = acc_w2;
+   }
+#endif
    if (resets) {
      if (refills) refill_pass_lds<ST>(a_wave, lane, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
      __syncthreads();   // the slots taken in the last step have been refilled
    }
   } else {
+#ifdef RDV_STAMPS
+   unsigned long long acc_w1 = 0, acc_tr = 0, acc_tail = 0, acc_w2 = 0;
+#endif
    for (int t = 0; t < T; ++t) {
+    ROLL_T(te0);
     __syncthreads();   // actions of step t are in LDS; every listed slot has been refilled
+    ROLL_T(te1);
+#ifdef RDV_STAMPS
+    unsigned long long te2 = 0;
+#endif
     {
       // ------------------------------------------------------------------ phase B: env transition
       int sl = slot, ln = lane;   // opaque copies: this loop's per-lane addresses are recomputed, not kept in registers across the rollout
@@ -234,6 +298,9 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[sl * RDV_ACT_DIM + j] : 0.0f;
       StepResult r;
       const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, it, active, e, a, r);   // kRaw: a rollout may start from an injected state
+#ifdef RDV_STAMPS
+      __builtin_amdgcn_sched_barrier(0); te2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
+#endif
       const bool fin = stepped && r.done;
       if (active) {
         A.reward[(int64_t)t * n + it] = r.reward;
@@ -242,6 +309,10 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       // episode statistics: the same wavefront reduction as rdv_step (same order of the fp64 sums), into the wave's LDS slot
       stats_update(my_stats, ln < 12 ? my_stats[ln] : 0ull, ln, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
       if (resets) {
+        // every slot listed in an earlier step has been refilled, and the refilling waves are done reading the job arrays: four
+        // signals per step (they were given ~2,300 cycles ago; the bound only keeps a lost signal from hanging the launch)
+        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(refills_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(kGroupWaves * (t + 1)); ++spin)
+          __builtin_amdgcn_s_sleep(2);
         if (fin) {
           SlotRaw<ST> raw;
           slot_fetch<ST>(L, sl, raw);
@@ -256,8 +327,19 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #pragma unroll
       for (int j = 0; j < RDV_OBS_DIM; ++j) obs_cur[sl * RDV_OBS_DIM + j] = r.obs[j];
     }
+    ROLL_T(te3);
     __syncthreads();   // observations of step t+1 are in LDS
+    ROLL_T(te4);
+#ifdef RDV_STAMPS
+    acc_w1 += te1 - te0; acc_tr += te2 - te1; acc_tail += te3 - te2; acc_w2 += te4 - te3;
+#endif
    }
+#ifdef RDV_STAMPS
+   if (A.stamps && lane == 0) {
+     unsigned long long* o = A.stamps + ((uint64_t)blockIdx.x * 12 + wv) * 8;
+     o[0] = acc_w1; o[1] = acc_tr; o[2] = acc_tail; o[3] = acc_w2;
+   }
+#endif
    if (resets) __syncthreads();   // the slots taken in the last step have been refilled (actor waves)
    // (the epilogue lives inside the env branch: after the join the env state would count as live across the actor loop too, and
    //  its 51 registers would be saved to scratch around it)
