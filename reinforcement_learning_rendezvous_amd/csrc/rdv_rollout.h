@@ -12,13 +12,17 @@
 //   - the current observations [256,17] and actions [256,6] are handed over through LDS; two workgroup barriers per step;
 //   - nothing is re-read from HBM between steps and there is no launch boundary: of the 19 us a policy_act + step pair takes
 //     at 65,536 envs, ~5 us are launch gaps and kernel entry/exit, and the state / observation round trips.
-// Phase A (actor waves): obs_t rows -> HBM; the actor of rdv_policy.h (bf16x3 MFMAs, register-resident), noise, clip -> LDS and HBM.
+// Phase A (actor waves): obs_t rows -> HBM; the actor of rdv_policy.h (bf16x3 MFMAs, register-resident), the sample from the noise
+// drawn one phase earlier, clip -> LDS and HBM.
 // Phase B (env waves): transition, reward/done -> HBM, obs_{t+1} -> LDS.  A lane whose episode ended copies its prepared slot
-// (rdv_slots.h; the workgroup's 256 slots live in LDS during the launch) — no reset arithmetic in the env phase.  The slots taken
-// in a step are refilled during the NEXT actor phase by actor waves 0-3 (one per SIMD; they carry no state between steps, so the
-// refill costs no registers — in the env waves, whose 51 state registers stay live, it spilled), each doing one PART (rc+vc | qc+wc
-// | qt | wt) for the same compacted list of ~13 envs: ~300 fp64 instructions per SIMD and step instead of a ~900-instruction reset
-// in ~96 % of the env waves inside the env phase (round 1: env phase 5.5 us against 2.5 us for the transition alone).
+// (rdv_slots.h; the workgroup's 256 slots live in LDS during the launch) — no reset arithmetic in the env phase.  BESIDE phase B the
+// actor waves, which would only wait there, do what does not depend on obs_{t+1}: waves 0-3 (one per SIMD; they carry no state
+// between steps, so it costs no registers — in the env waves, whose 51 state registers stay live, it spilled) refill the slots taken
+// in step t-1, each doing one PART (rc+vc | qc+wc | qt | wt) for the same compacted list of ~13 envs, and count themselves done in LDS
+// (the env waves read that counter before they take a slot or rewrite the job arrays: an env can finish in consecutive steps); all
+// eight draw the exploration noise of step t+1 (Philox + Box-Muller) into their staging rows.  Round 2 moved both out of phase A
+// (stamps, tools/rollout_stamps.py: phase A 18.9k -> 16.4k cycles of a 26.9k-cycle step).  Round 1 ran the whole ~900-instruction
+// reset in ~96 % of the env waves inside the env phase (5.5 us against 2.5 us for the transition alone).
 // (Measured and dropped, all bit-identical in results: (a) preparing every env's next initial state in LDS while the env waves wait
 // for the actor — the vector pipe is the shared resource of both phases, so the fp64 filler work lengthens the actor phase by what
 // it takes off the env phase (13.3 -> 13.6 us per step); (b) actor waves 0-3 doubling as service waves during the env phase, as in
