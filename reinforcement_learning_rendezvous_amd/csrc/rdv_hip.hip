@@ -170,8 +170,11 @@ __device__ __forceinline__ void load_actions(const float* __restrict__ actions, 
   wave_lds_fence();   // the region is reused for the observations
 }
 
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
 // observations [64,17] of one wave: staged rows in LDS -> contiguous 16-byte-per-lane global stores
 // (`aligned`: dst is 16-byte aligned — always for [N,17] rows of a 64-env wave, for row t of a [T,N,17] tape only if N % 4 == 0)
+// kStream: non-temporal stores (the split kernel: see there)
+template <bool kStream = false>
 __device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t wave_base, int64_t rows, int lane, const float* wl,
                                                bool aligned = true) {
   if (rows <= 0) return;
@@ -180,11 +183,13 @@ __device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int q = k * kWave + lane;
-      *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
+      if (kStream) __builtin_nontemporal_store(*reinterpret_cast<const nt_f4*>(wl + 4 * q), reinterpret_cast<nt_f4*>(dst + 4 * q));
+      else *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
     }
     if (lane < 16) {
       const int q = 4 * kWave + lane;
-      *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
+      if (kStream) __builtin_nontemporal_store(*reinterpret_cast<const nt_f4*>(wl + 4 * q), reinterpret_cast<nt_f4*>(dst + 4 * q));
+      else *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
     }
   } else {   // ragged tail wave
     const int64_t valid = rows * RDV_OBS_DIM;
@@ -514,6 +519,10 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
 // speculative work at all: 8.2 us against 7.8 at 65,536 envs, 6.7 against 5.8 at 16,384.  The part is serial work after the barrier;
 // the speculative reset costs nothing on the chain.  Wave priorities — s_setprio on the step waves, or on the service waves — change
 // nothing either: 7.81-7.85 us in every combination.)
+// The observation rows leave this kernel with non-temporal stores (store_obs_rows<true>): measured with tools/lib_ab.py, same box,
+// alternating child processes — 7.54 -> 7.13 us per launch at 65,536 envs, 6.24 -> 6.08 at 32,768; non-temporal LOADS of the actions
+// cost 0.4 us, non-temporal stores of reward / done / reason change nothing, and at 524,288 envs (fused kernel) streaming rows lose
+// 1 %.  With the actor kernel reading the rows in the next launch (rdv_policy_act + rdv_step per step) the pair is unchanged, 15.8 us.
 constexpr int kSplitEnvs = 256;      // envs per workgroup
 constexpr int kSplitBlock = 512;     // 8 waves
 
@@ -573,7 +582,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
     store_step_outputs<true>(A, i, active, fin, r, e);
     if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-    if (m_reset == 0ull) store_obs_rows(A.obs, wave_base, rows, lane, wl);
+    if (m_reset == 0ull) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
     RDV_STAMP(5);
     if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
     RDV_STAMP(6);
@@ -607,7 +616,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
       }
       wave_lds_fence();
-      store_obs_rows(A.obs, wave_base, rows, lane, wl);
+      store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
     }
     RDV_STAMP(6);
   }

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Diagnostic: A/B of two builds of the library (the product .so against an experimental one) on the one-launch step at 65,536 envs
+and 524,288 envs: each build in its own child process, alternated, 256-launch graphs under sustained load.
+    python tools/lib_ab.py tools/_nt.so"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CHILD = r'''
+import os, sys, time
+sys.path.insert(0, %r)
+import torch
+from reinforcement_learning_rendezvous_amd import _native
+if sys.argv[1] != "-":
+    _native.LIB_PATH = sys.argv[1]
+from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
+for n in (65536, 32768):
+    env = RendezvousBatch(n, device="cuda:0", storage="f32", seed=0)
+    g0 = torch.Generator(device="cuda:0").manual_seed(1)
+    acts = [(torch.rand((n, 6), device="cuda:0", generator=g0) * 2 - 1).contiguous() for _ in range(16)]
+    env.reset()
+    for t in range(32): env.step(acts[t %% 16])
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for t in range(256): env.step(acts[t %% 16])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.2:
+        g.replay(); torch.cuda.synchronize()
+    R = 100
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(R): g.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{n}: {e0.elapsed_time(e1) * 1e3 / (R * 256):.3f}", end="  ")
+    if n == 65536:      # the closed loop as two launches per step: the observation rows are read by the actor kernel next
+        from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+        pol = MlpPolicy.from_npz(os.path.join('/root/repo', "tests", "golden", "mlp_policy.npz")).to("cuda:0")
+        buf = torch.empty((n, 6), dtype=torch.float32, device="cuda:0")
+        for t in range(16): env.step(pol.act(env.obs, deterministic=False, out=buf))
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2):
+            for t in range(64): env.step(pol.act(env.obs, deterministic=False, out=buf))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.2:
+            g2.replay(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(60): g2.replay()
+        e1.record(); torch.cuda.synchronize()
+        print(f"act+step pair: {e0.elapsed_time(e1) * 1e3 / (60 * 64):.3f}", end="  ")
+        pol.close()
+    env.close()
+print()
+''' % ROOT
+others = sys.argv[1:]
+for rep in range(2):
+    for label, lib in [("product", "-")] + [(os.path.basename(o), o) for o in others]:
+        r = subprocess.run([sys.executable, "-c", CHILD, lib], capture_output=True, text=True, timeout=300)
+        print(f"{label:10s} us per launch  {r.stdout.strip()}" + ("" if r.returncode == 0 else " FAILED " + r.stderr[-300:]), flush=True)

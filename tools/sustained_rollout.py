@@ -7,15 +7,17 @@ import torch
 from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
 from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
 n, T = 65536, 64
-det = len(sys.argv) > 1 and sys.argv[1] == "det"
+det = "det" in sys.argv[1:]
+storage = "f64" if "f64" in sys.argv[1:] else "f32"
+blocks = 3 if "short" in sys.argv[1:] else 8
 pol = MlpPolicy.from_npz(os.path.join(ROOT, "tests", "golden", "mlp_policy.npz")).to("cuda:0")
-env = RendezvousBatch(n, device="cuda:0", storage="f32", seed=0)
+env = RendezvousBatch(n, device="cuda:0", storage=storage, seed=0)
 env.reset()
 out = env.rollout(pol, T, deterministic=det)
 torch.cuda.synchronize()
 time.sleep(1.5)
-print(f"start {time.time():.2f} deterministic={det}", flush=True)
-for block in range(8):
+print(f"start {time.time():.2f} deterministic={det} storage={storage}", flush=True)
+for block in range(blocks):
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(41)]
     ev[0].record()
     for c in range(40):
