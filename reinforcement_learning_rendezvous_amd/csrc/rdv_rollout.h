@@ -199,7 +199,8 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             const int q = k * 64 + ln;
-            if (q < kPolWaveEnvs * RDV_OBS_DIM / 4) *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(xin + 4 * q);
+            if (q < kPolWaveEnvs * RDV_OBS_DIM / 4)   // written once: non-temporal
+              __builtin_nontemporal_store(*reinterpret_cast<const nt_f4*>(xin + 4 * q), reinterpret_cast<nt_f4*>(dst + 4 * q));
           }
         } else {
           const int64_t valid = a_rows * RDV_OBS_DIM;

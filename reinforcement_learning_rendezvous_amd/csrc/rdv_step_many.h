@@ -151,7 +151,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
 #pragma unroll
       for (int j = 0; j < RDV_OBS_DIM; ++j) my_obs[lane * RDV_OBS_DIM + j] = r.obs[j];
       wave_lds_fence();
-      store_obs_rows(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs, vec_rows);
+      store_obs_rows<true>(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs, vec_rows);   // written once: non-temporal
       wave_lds_fence();   // the rows are rewritten by the next step
     }
     if (active) store_env<ST>(ws, A.cs, i, e, wt_dirty);
