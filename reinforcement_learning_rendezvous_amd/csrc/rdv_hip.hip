@@ -521,7 +521,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
 // nothing either: 7.81-7.85 us in every combination.)
 // The observation rows leave this kernel with non-temporal stores (store_obs_rows<true>): measured with tools/lib_ab.py, same box,
 // alternating child processes — 7.54 -> 7.13 us per launch at 65,536 envs, 6.24 -> 6.08 at 32,768; non-temporal LOADS of the actions
-// cost 0.4 us, non-temporal stores of reward / done / reason change nothing, and at 524,288 envs (fused kernel) streaming rows lose
+// cost 0.4 us, non-temporal stores of reward / done / reason or of the state change nothing, and at 524,288 envs (fused kernel) streaming rows lose
 // 1 %.  With the actor kernel reading the rows in the next launch (rdv_policy_act + rdv_step per step) the pair is unchanged, 15.8 us.
 constexpr int kSplitEnvs = 256;      // envs per workgroup
 constexpr int kSplitBlock = 512;     // 8 waves
