@@ -105,7 +105,7 @@ def _run_episodes(policy, env, states, deterministic, generator=None, act=None):
     p = env.params
     assert states.shape[0] == env.num_envs, (states.shape[0], env.num_envs)
     env.reset()                                                                      # :106 (flags of the nominal state stay, :107-112)
-    env.set_state(torch.from_numpy(states))
+    env.set_state(states if isinstance(states, torch.Tensor) else torch.from_numpy(states))
     obs = env.observe()                                                              # :113
     env.eval_begin()                                                                 # :117-123
     for _ in range(episode_steps_bound(p)):                                          # :126
@@ -143,12 +143,13 @@ def run(policy, initial_states, device="cuda:0", storage="f32", config=None, det
 REPLICA_COLUMNS = COLUMNS          # the stochastic replicas keep all twelve columns (the terminal errors need no error history)
 
 
-def evaluate_replicas(policy, env, states):
+def evaluate_replicas(policy, env, states, normalised=False):
     """Stochastic-action trajectories (SB3 ``predict(deterministic=False)``: mean + exp(log_std) N(0,1), clipped) from the given
-    initial states, one per env of the halting batch ``env``, the exploration noise keyed by the batch's global env ids."""
+    initial states (a NumPy array, or a tensor already on the batch's device), one per env of the halting batch ``env``, the
+    exploration noise keyed by the batch's global env ids.  ``normalised``: the quaternions of ``states`` are unit already."""
     offset = getattr(env, "env_id_offset", None)
     act = (lambda obs: policy.act(obs, deterministic=False, env_id_offset=offset)) if offset is not None else None
-    return _run_episodes(policy, env, _normalised(states), False, act=act)
+    return _run_episodes(policy, env, states if normalised else _normalised(states), False, act=act)
 
 
 def run_replicas(policy, initial_states, replicas, device="cuda:0", storage="f32", config=None, seed=0, rank=0, world=1,
@@ -169,7 +170,13 @@ def run_replicas(policy, initial_states, replicas, device="cuda:0", storage="f32
     else:
         env = engine_factory(hi - lo, params)
     policy.noise_seed, policy.noise_env_offset, policy._calls = int(seed), lo, 0      # (engines without env_id_offset: tests)
-    out = evaluate_replicas(policy, env, ics[np.arange(lo, hi) % m])
+    unit = _normalised(ics)                     # the M distinct rows, once; trajectory g starts from row g mod M
+    if engine_factory is None:                  # tiled on the device: 10^6 x 20 doubles never exist on the host
+        rows = torch.arange(lo, hi, device=env.device) % m
+        states = torch.from_numpy(unit).to(env.device).index_select(0, rows)
+    else:
+        states = unit[np.arange(lo, hi) % m]
+    out = evaluate_replicas(policy, env, states, normalised=True)
     if hasattr(env, "close"):
         env.close()
     return out, (lo, hi)
