@@ -41,6 +41,10 @@ constexpr int kStatWords = 16;          // 128-byte slot per wave
 // environment at rdv_create forces it off / on (diagnostics).
 constexpr int64_t kXcdOrderMaxEnvs = 3145728;
 static inline bool xcd_order_by_size(int64_t n) { return n <= kXcdOrderMaxEnvs && n % 65536 == 0; }
+// Fused kernel: the observation rows leave with non-temporal stores up to this size (tools/lib_ab.py, same box, alternating child
+// processes, us per launch plain -> streamed): 98,304 envs 11.02 -> 10.69, 131,072 11.48 -> 11.19, 196,608 14.8 -> 13.6, 262,144
+// 22.57 -> 21.24, 327,680 26.98 -> 26.57, 393,216 30.9 -> 30.1; 458,752 and 524,288 +-2 % either way, 786,432 57.7 -> 61.6 (worse).
+constexpr int64_t kStreamRowsMaxEnvs = 393216;
 constexpr int64_t kSplitAutoMaxEnvs = 65536;    // measured crossover (tools/n_sweep.py, profiles/r02_n_sweep_parts.csv): split wins up to one 256-env workgroup per CU
 enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
        ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
@@ -137,7 +141,8 @@ struct StepArgs {
   int32_t on_done;
   void* prep;               // prepared next-episode states of the persistent kernels (csrc/rdv_slots.h): one record per env
   uint32_t* prep_tag;       // [N]
-  int32_t xcd_per;          // step_kernel_parts: workgroups per XCD region (0: plain block order)
+  int32_t xcd_per;          // fused kernels: workgroups per XCD region (0: plain block order)
+  int32_t stream_rows;      // fused kernels: store the observation rows non-temporally (kStreamRowsMaxEnvs)
 #ifdef RDV_STAMPS
   unsigned long long* stamps;
 #endif
@@ -393,7 +398,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
 #pragma unroll
   for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
   wave_lds_fence();
-  store_obs_rows(A.obs, wave_base, rows, lane, wl);
+  if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see kStreamRowsMaxEnvs
+  else store_obs_rows<false>(A.obs, wave_base, rows, lane, wl);
   // state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt, or always when wt evolves)
   if (stepped) store_env<ST>(ws, A.cs, i, e, did_reset || kGeneral);
 }
@@ -495,7 +501,8 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
   } else {
     wave_lds_fence();
   }
-  store_obs_rows(A.obs, wave_base, rows, lane, wl);
+  if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see kStreamRowsMaxEnvs
+  else store_obs_rows<false>(A.obs, wave_base, rows, lane, wl);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1408,6 +1415,7 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
     if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
   } else {
     dim3 grid = grid_for(h->n), block(kBlock);
+    A.stream_rows = h->n <= kStreamRowsMaxEnvs ? 1 : 0;
     if (h->xcd_order == 1 || (h->xcd_order < 0 && xcd_order_by_size(h->n))) {
       A.xcd_per = (int32_t)((grid.x + 7) / 8);
       grid = dim3((unsigned)A.xcd_per * 8u);   // up to 7 padding workgroups, which find no envs
