@@ -155,24 +155,18 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// actions [64,6] of one wave: 3 coalesced float2 loads per lane -> wave-private LDS -> own row
-__device__ __forceinline__ void load_actions(const float* __restrict__ actions, int64_t wave_base, int64_t rows, int lane,
-                                             bool active, float* wl, float* a) {
-  const float* src = actions + wave_base * RDV_ACT_DIM;
-  const int64_t valid = rows * RDV_ACT_DIM;
+// actions [64,6] of one wave: every lane loads its own row straight into registers, three 8-byte loads at a 24-byte lane stride (the
+// wave's rows are 1.5 KB contiguous, so the three instructions touch the same twelve lines a staged, lane-contiguous copy would).
+// Round 1 staged the rows through LDS for lane-contiguous loads; the round trip (write, fence, six reads) sat on the critical chain:
+// 7.14 -> 6.84 us per launch at 65,536 envs, 13.5 -> 12.8 at 196,608 (tools/lib_ab.py).
+__device__ __forceinline__ void load_actions(const float* __restrict__ actions, int64_t wave_base, int lane, bool active, float* a) {
+  const float* row = actions + (wave_base + lane) * RDV_ACT_DIM;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const int idx = k * 128 + lane * 2;
-    if (idx + 1 < valid) {
-      *reinterpret_cast<float2*>(wl + idx) = *reinterpret_cast<const float2*>(src + idx);
-    } else if (idx < valid) {
-      wl[idx] = src[idx];
-    }
+    float2 v = make_float2(0.0f, 0.0f);
+    if (active) v = *reinterpret_cast<const float2*>(row + 2 * k);
+    a[2 * k] = v.x; a[2 * k + 1] = v.y;
   }
-  wave_lds_fence();
-#pragma unroll
-  for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? wl[lane * RDV_ACT_DIM + j] : 0.0f;
-  wave_lds_fence();   // the region is reused for the observations
 }
 
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
@@ -374,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
   const uint64_t slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;
   float a[RDV_ACT_DIM];
-  load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+  load_actions(A.actions, wave_base, lane, active, a);
 
   StepResult r;
   const bool stepped = advance<ST, kDiag, kGeneral, kRaw>(A, P, i, active, e, a, r);
@@ -475,7 +469,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
     const uint64_t slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;   // (a padding workgroup of the XCD order has no envs)
     float a[RDV_ACT_DIM];
-    load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+    load_actions(A.actions, wave_base, lane, active, a);
     StepResult r;
     const bool stepped = advance<ST, false, false, false>(A, P, i, active, e, a, r);
     const bool fin = stepped && r.done;
@@ -542,7 +536,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
   StepArgs A = A_rest;
   A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
   using V = typename Vec4<ST>::type;
-  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // actions, then observation rows
+  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // observation rows
   __shared__ unsigned long long fin_mask[kSplitEnvs / kWave];                        // per step wave: lanes to reset
   const DevParams& P = *Pp;   // scalar loads: see step_kernel
   const int lane = threadIdx.x & (kWave - 1);
@@ -568,7 +562,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
     const uint64_t slot_pre = stats_preload(slot, lane);
     float a[RDV_ACT_DIM];
-    load_actions(A.actions, wave_base, rows, lane, active, wl, a);
+    load_actions(A.actions, wave_base, lane, active, a);
     RDV_STAMP(1);
     const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
     RDV_STAMP(2);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
   using V = typename Vec4<ST>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* obs_rows = lds;                                                           // [256][17]
-  float* act_rows = obs_rows + kManyEnvs * RDV_OBS_DIM;                            // [256][6]
+  float* act_rows = obs_rows + kManyEnvs * RDV_OBS_DIM;                            // [256][6] (unused since the action rows are loaded straight into registers; kept in the layout)
   uint32_t* job_kind = reinterpret_cast<uint32_t*>(act_rows + kManyEnvs * RDV_ACT_DIM);   // [256]
   uint32_t* job_counter = job_kind + kManyEnvs;                                    // [256]
   uint64_t* stat_lds = reinterpret_cast<uint64_t*>(job_counter + kManyEnvs);       // [4][16]
@@ -80,7 +80,6 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     // ------------------------------------------------------------------ env waves
     __builtin_amdgcn_s_setprio(2);
     float* my_obs = obs_rows + (slot - lane) * RDV_OBS_DIM;
-    float* my_act = act_rows + (slot - lane) * RDV_ACT_DIM;
     uint64_t* my_stats = stat_lds + wv * kStatWords;
     if (lane < kStatWords) my_stats[lane] = 0ull;
     const SlotStore<ST> H = hbm_slot_store<ST>(A.prep);   // the slots in HBM
@@ -99,30 +98,21 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     }
     StepArgs SA;
     SA.diag = nullptr;
-    // the wave's action rows [64][6] of one step are 384 contiguous floats: 3 x float2 per lane
+    // the lane's own action row of one step: three 8-byte loads straight into registers (see load_actions)
     auto fetch = [&](int k, float2 (&pre)[3]) {
-      const float* src = A.actions + ((int64_t)k * n + wave_base) * RDV_ACT_DIM;
-      const int64_t valid = rows * RDV_ACT_DIM;
+      const float* row = A.actions + ((int64_t)k * n + i) * RDV_ACT_DIM;
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        const int idx = q * 128 + lane * 2;
-        pre[q] = make_float2(0.0f, 0.0f);
-        if (idx + 1 < valid) pre[q] = *reinterpret_cast<const float2*>(src + idx);
-        else if (idx < valid) pre[q].x = src[idx];
-      }
+      for (int q = 0; q < 3; ++q) pre[q] = active ? *reinterpret_cast<const float2*>(row + 2 * q) : make_float2(0.0f, 0.0f);
     };
     float2 pre[3] = {make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f), make_float2(0.0f, 0.0f)};
-    if (rows > 0) fetch(0, pre);
+    fetch(0, pre);
     if (resets) __syncthreads();   // S0: the slots and the entry jobs are in LDS
     for (int k = 0; k < K; ++k) {
-      // actions of this step: registers -> LDS rows -> own row; then request the next step's while this one computes
-#pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<float2*>(my_act + q * 128 + lane * 2) = pre[q];
-      wave_lds_fence();
+      // actions of this step (requested a step ago); then request the next step's while this one computes
       float a[RDV_ACT_DIM];
 #pragma unroll
-      for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? my_act[lane * RDV_ACT_DIM + j] : 0.0f;
-      if (rows > 0 && k + 1 < K) fetch(k + 1, pre);
+      for (int q = 0; q < 3; ++q) { a[2 * q] = pre[q].x; a[2 * q + 1] = pre[q].y; }
+      if (k + 1 < K) fetch(k + 1, pre);
       StepResult r;
       const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, i, active, e, a, r);   // kRaw: the tape may start from an injected state
       const bool fin = stepped && r.done;
