@@ -589,10 +589,13 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     RDV_STAMP(6);
   } else {
     // ------------------------------------------------------------------ service waves
-    V packed[7];               // the next initial state, already in storage layout: nothing is left to compute after the barrier
-    float robs[RDV_OBS_DIM];
+    // The observation and the storage packing of the next initial state are computed after the barrier, by the lanes that use them:
+    // since the action rows stopped travelling through LDS the service waves are the last to reach the barrier (stamps: ~7,100
+    // cycles after entry against ~5,800 for the step waves), and every instruction taken out of their path before it counts
+    // (tools/lib_ab.py: 6.88 -> 6.78 us per launch at 65,536 envs, 5.58 -> 5.36 at 16,384).  Deferring more — the target's rate, with
+    // its rotation matrix — overshoots: 7.05 us.
+    Env ne;
     if (resets && active) {
-      Env ne;
       const V c5 = ws[5 * A.cs + i];
       ne.episode = s2u(c5.w);
       RDV_STAMP(1);
@@ -600,8 +603,6 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
       reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
       reset_aux<ST>(P, ne);
-      observation(P, ne, robs);
-      pack_env<ST>(ne, packed);
       RDV_STAMP(2);
     }
     RDV_STAMP(3);
@@ -611,8 +612,9 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     if (m_reset != 0ull) {   // wave-uniform: some env of the step wave we serve finished its episode
       float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
       if (active && ((m_reset >> lane) & 1ull)) {
-        // auto-reset (SB3 DummyVecEnv semantics): the new state to HBM, the first observation of the next episode into the row
-        store_chunks<ST>(ws, A.cs, i, packed, true);
+        float robs[RDV_OBS_DIM];
+        observation(P, ne, robs);
+        store_env<ST>(ws, A.cs, i, ne, true);
 #pragma unroll
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
       }
