@@ -503,9 +503,9 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
 // Split-role variant for a chip that is NOT full (N <= ~98k envs: one transition wave per SIMD): a 512-thread workgroup owns 256
 // envs.  Waves 0-3 ("step waves") do the whole transition for their 64 envs exactly as the fused kernel does, except the in-lane
 // reset.  Waves 4-7 ("service waves") run beside them — an 8-wave workgroup places waves w and w+4 on the same SIMD, so every SIMD
-// holds one of each — and compute every env's NEXT initial state and observation IN REGISTERS while the step runs (they depend only
-// on seed, env id and episode index).  After the single workgroup barrier a service lane whose env finished writes that state and
-// observation straight to HBM; the step waves have nothing left to do.  Same arithmetic, same results as the fused variant.
+// holds one of each — and compute every env's NEXT initial state IN REGISTERS while the step runs (it depends only on seed, env id
+// and episode index).  After the single workgroup barrier a service lane whose env finished forms the observation of that state and
+// writes both straight to HBM; the step waves have nothing left to do.  Same arithmetic, same results as the fused variant.
 // The next-state work is done for every env and used by ~5 %.  Round 2 built the alternative the first review asked for — the next
 // state persisted in HBM per env (rdv_slots.h), copied where an episode ends and refilled once per episode by compacted passes —
 // for this kernel and for the fused one, and measured it (profiles/r02_*): 8.2 us per launch against 7.3 for this form at 65,536
