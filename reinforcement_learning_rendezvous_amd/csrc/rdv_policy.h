@@ -58,13 +58,21 @@ static_assert(kPolFloats % 4 == 0, "the parameter block is copied as float4");
 constexpr int kPolObsStage = kPolWaveEnvs * kPolIn, kPolActStage = kPolWaveEnvs * kPolOut;
 constexpr int kPolLdsBytes = (kPolFloats + (kPolBlock / 64) * (kPolObsStage + kPolActStage)) * 4;   // 73,440 B: two workgroups per CU
 
-// tanh in fp32 as copysign(1 - 2 / (2^(2 log2(e) |x|) + 1), x): v_exp_f32 + v_rcp_f32 (1 ulp each) and four plain VALU ops.
-// Absolute error <= ~2.5e-7 everywhere (cancellation near 0 costs relative, not absolute, accuracy; what feeds the next layer's
-// sums is the absolute error, the same size as the rounding of an activation near 1)
-__device__ __forceinline__ float tanh_f32(float x) {
-  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * fabsf(x));   // inf for |x| > 44: the result is then exactly +-1
-  const float r = __builtin_amdgcn_rcpf(e + 1.0f);
-  return copysignf(fmaf(-2.0f, r, 1.0f), x);
+// tanh in fp32 as 1 - 2 / (2^(2 log2(e) x) + 1), two at a time: v_exp_f32 + v_rcp_f32 (1 ulp each) per value and one packed multiply,
+// add and fma per pair (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  On x itself, without |x| and copysign: the power underflows
+// to 0 for x << 0 (-> exactly -1) and overflows to inf for x >> 0 (-> exactly +1).  Absolute error <= ~2.5e-7 everywhere
+// (cancellation near 0 costs relative, not absolute, accuracy; what feeds the next layer's sums is the absolute error, the same size
+// as the rounding of an activation near 1).  Round 2: the |x| / copysign form cost a v_bfi_b32 per value and kept the multiply
+// unpacked; with both gone the rollout kernel's closed-loop step went from 10.26 to 9.22 us (tools/lib_ab_persist.py).
+typedef float pol_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tanh2_f32(float x0, float x1, float& t0, float& t1) {
+  const pol_f2 x = {x0, x1};
+  const pol_f2 y = x * 2.8853900817779268f;
+  const pol_f2 e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
+  const pol_f2 s1 = e + 1.0f;
+  const pol_f2 r = {__builtin_amdgcn_rcpf(s1.x), __builtin_amdgcn_rcpf(s1.y)};
+  const pol_f2 t = __builtin_elementwise_fma(pol_f2{-2.0f, -2.0f}, r, pol_f2{1.0f, 1.0f});
+  t0 = t.x; t1 = t.y;
 }
 
 // two standard normals from two 32-bit words (Box-Muller, fp32)
@@ -135,10 +143,10 @@ __device__ __forceinline__ void layer(const float* w, int frag0, const float* bi
 __device__ __forceinline__ void activate(const f32x16& d, bf16x8 (&lo_step)[3], bf16x8 (&hi_step)[3]) {
   float x[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = tanh_f32(d[j]);
+  for (int j = 0; j < 8; j += 2) tanh2_f32(d[j], d[j + 1], x[j], x[j + 1]);
   split3(x, lo_step);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = tanh_f32(d[8 + j]);
+  for (int j = 0; j < 8; j += 2) tanh2_f32(d[8 + j], d[9 + j], x[j], x[j + 1]);
   split3(x, hi_step);
 }
 
