@@ -38,6 +38,7 @@ constexpr int kPolBlockEnvs = (kPolBlock / 64) * kPolWaveEnvs;   // 256
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float pol_f4 __attribute__((ext_vector_type(4)));
+typedef float pol_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // Packed parameter block (built by rdv_policy_create, copied to LDS by every workgroup).  bf16 section: weight FRAGMENTS of
@@ -64,7 +65,6 @@ constexpr int kPolLdsBytes = (kPolFloats + (kPolBlock / 64) * (kPolObsStage + kP
 // (cancellation near 0 costs relative, not absolute, accuracy; what feeds the next layer's sums is the absolute error, the same size
 // as the rounding of an activation near 1).  Round 2: the |x| / copysign form cost a v_bfi_b32 per value and kept the multiply
 // unpacked; with both gone the rollout kernel's closed-loop step went from 10.26 to 9.22 us (tools/lib_ab_persist.py).
-typedef float pol_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void tanh2_f32(float x0, float x1, float& t0, float& t1) {
   const pol_f2 x = {x0, x1};
   const pol_f2 y = x * 2.8853900817779268f;
@@ -90,7 +90,9 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// x[j] = hi[j] + mid[j] + lo[j] to 24 bits; each subtraction is exact in fp32
+// x[j] = hi[j] + mid[j] + lo[j] to 24 bits; each subtraction is exact in fp32.  (Written on 2-vectors — packed converts, packed subtracts,
+// 56 instructions fewer per wave — the standalone actor gains 1 % and the rollout kernel LOSES 6 %, 9.26 -> 9.87 us per step: there the
+// order in which the scheduler interleaves this with the dependent MFMA chains matters more than the count.  Kept scalar.)
 __device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&t)[3]) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
