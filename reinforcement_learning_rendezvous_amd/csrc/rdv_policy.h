@@ -130,10 +130,11 @@ __device__ __forceinline__ void layer(const float* w, int frag0, const float* bi
       const float4 b = *reinterpret_cast<const float4*>(biasp + (mt * 2 + h) * 16 + 4 * e4);
       d[mt][4 * e4 + 0] = b.x; d[mt][4 * e4 + 1] = b.y; d[mt][4 * e4 + 2] = b.z; d[mt][4 * e4 + 3] = b.w;
     }
+  // row tile outermost: tile 0 is complete, and its activation can start, while the matrix pipe still works on tile 1
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+    for (int ks = 0; ks < KS; ++ks) {
       bf16x8 a[3];
 #pragma unroll
       for (int q = 0; q < 3; ++q) a[q] = wf[(frag0 + (q * MT + mt) * KS + ks) * 64];
