@@ -116,9 +116,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
   // ---- env waves: state -> registers, first observation -> LDS
   const int slot = (wv & (kRollEnvWaves - 1)) * kWave + lane;     // env waves: the env of this lane
   const int64_t i = block_base + slot;
-  const int64_t wave_base = i - lane;
   const bool active = env_role && i < n;
-  const int64_t env_rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
   Env e;
   e.episode = 0u;
   bool wt_dirty = kGeneral;  // the target's rate is constant between resets for the reference's bodies, not for general ones
@@ -348,19 +346,26 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
    if (resets) __syncthreads();   // the slots taken in the last step have been refilled (actor waves)
    // (the epilogue lives inside the env branch: after the join the env state would count as live across the actor loop too, and
    //  its 51 registers would be saved to scratch around it)
-    // ---- the observation after the last step, the state, the slots that changed and the statistics go back to HBM
-    store_obs_rows(A.last_obs, wave_base, env_rows, lane, obs_cur + (slot - lane) * RDV_OBS_DIM);
-    if (active) store_env<ST>(reinterpret_cast<V*>(A.ws), A.cs, i, e, wt_dirty);
+    // ---- the observation after the last step, the state, the slots that changed and the statistics go back to HBM.  The env / row
+    // indices are re-derived here from an opaque copy of the slot index: as values computed before the loop they would be carried
+    // across it, and at this kernel's register budget that meant three dwords of scratch
+    int sl_e = slot;
+    asm volatile("" : "+v"(sl_e));
+    const int ln_e = sl_e & (kWave - 1);
+    const int64_t i_e = block_base + sl_e, wb_e = i_e - ln_e;
+    const int64_t rows_e = (n - wb_e) < kWave ? (n - wb_e) : kWave;
+    store_obs_rows(A.last_obs, wb_e, rows_e, ln_e, obs_cur + (sl_e - ln_e) * RDV_OBS_DIM);
+    if (active) store_env<ST>(reinterpret_cast<V*>(A.ws), A.cs, i_e, e, wt_dirty);
     if (active && slot_dirty) {
-      slot_copy<ST>(H, i, L, slot);
-      A.prep_tag[i] = e.episode + 1u;
+      slot_copy<ST>(H, i_e, L, sl_e);
+      A.prep_tag[i_e] = e.episode + 1u;
     }
-    if (env_rows > 0 && lane < 12) {   // this wave's statistics slot in HBM += the rollout's (counters as integers, sums as fp64)
-      uint64_t* slot_stats = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-      const uint64_t pre = slot_stats[lane], add = my_stats[lane];
+    if (rows_e > 0 && ln_e < 12) {   // this wave's statistics slot in HBM += the rollout's (counters as integers, sums as fp64)
+      uint64_t* slot_stats = A.stats + (uint64_t)(wb_e / kWave) * kStatWords;
+      const uint64_t pre = slot_stats[ln_e], add = my_stats[ln_e];
       const uint64_t as_int = pre + add;
       const uint64_t as_real = (uint64_t)__double_as_longlong(__longlong_as_double((long long)pre) + __longlong_as_double((long long)add));
-      slot_stats[lane] = lane <= ST_SUM_LEN ? as_int : as_real;
+      slot_stats[ln_e] = ln_e <= ST_SUM_LEN ? as_int : as_real;
     }
   }
 }
