@@ -355,6 +355,28 @@ def main():
         except Exception as exc:  # pragma: no cover
             out["large_n"] = {"error": repr(exc)}
 
+    # ---- informational: BASELINE config 4's GLOBAL batch (524,288 envs = 8 shards of 65,536) stepped by ONE GPU (fused kernel)
+    if rank == 0 and world == 1 and not args.no_large_n:
+        try:
+            n_mid = 524288
+            gen_m = torch.Generator(device=device).manual_seed(77)
+            acts_m = [(torch.rand((n_mid, 6), device=device, generator=gen_m) * 2 - 1).contiguous() for _ in range(4)]
+            mid = RendezvousBatch(n_mid, device=device, storage=args.storage, seed=0)
+            mid.reset()
+            for t in range(24):
+                mid.step(acts_m[t % 4])
+            us_mid = timed_steps(mid, acts_m, 64, 9)
+            ach_m = ALGO_BYTES_PER_ENV_STEP * n_mid / (us_mid * 1e-6) / 1e9
+            out["config4_global_batch_on_one_gpu"] = {"value": n_mid / (us_mid * 1e-6), "unit": "env steps/s", "envs": n_mid, "launch_us": us_mid,
+                                                      "kernel": "rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>"),
+                                                      "roofline": {"bound": "hbm", "achieved": ach_m, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                                                   "frac": ach_m / HBM_PEAK_GBPS, "traffic": None},
+                                                      "note": "154 MB of state + I/O per launch: within the 256 MiB Infinity Cache"}
+            mid.close(); del mid, acts_m
+            torch.cuda.empty_cache()
+        except Exception as exc:  # pragma: no cover
+            out["config4_global_batch_on_one_gpu"] = {"error": repr(exc)}
+
     # ---- informational: the same open-loop workload as K steps per persistent launch (rdv_step_many) — NOT the headline shape
     if rank == 0 and world == 1:
         try:
