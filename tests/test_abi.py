@@ -157,3 +157,30 @@ def test_constructor_and_make_env_surface_reproduce_the_reference():
         got = np.concatenate([np.atleast_1d(np.asarray(p.to_dict()[n], dtype=np.float64)) for n, _ in EnvParams._fields_])
         np.testing.assert_allclose(got, want, rtol=1e-15, atol=0, err_msg=str(note))
         assert N.lib().rdv_params_validate(C.byref(p)) == 0
+
+
+def test_training_kernels_use_no_scratch():
+    """The kernels of the training paths keep everything in registers: `make resource` (hipcc's kernel-resource remarks, gfx950
+    cross-compile, no GPU needed) must report ScratchSize 0 for the one-launch step kernels, the actor and the persistent kernels
+    with the reference's bodies.  (The general rigid-body instantiations of the persistent kernels, per-lane RK45 at their register
+    budget, do spill and are not in this list.)"""
+    csrc = os.path.join(os.path.dirname(N.__file__), "csrc")
+    r = subprocess.run(["make", "-C", csrc, "resource"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = r.stdout + r.stderr
+    scratch = {}
+    name = None
+    for line in text.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name:
+            scratch[name] = int(m.group(1))
+    want = ["step_kernel_splitIf", "step_kernel_splitId", "step_kernel_partsIf", "step_kernel_partsId", "step_kernelIfLb0ELb0ELb0",
+            "step_kernelIdLb0ELb0ELb0", "policy_act_kernel", "policy_value_kernel", "rollout_kernelIfLb0", "rollout_kernelIdLb0",
+            "step_many_kernelIfLb0", "step_many_kernelIdLb0"]
+    for w in want:
+        hits = {k: v for k, v in scratch.items() if w in k}
+        assert hits, f"no kernel matching {w} in the resource report"
+        assert all(v == 0 for v in hits.values()), (w, hits)
