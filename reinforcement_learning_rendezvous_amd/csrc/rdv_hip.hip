@@ -619,6 +619,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
       }
       wave_lds_fence();
+      RDV_STAMP(5);
       store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
     }
     RDV_STAMP(6);
