@@ -3,8 +3,10 @@
 bench.py — env steps/sec of the fused rendezvous step on MI355X (BASELINE.json metric).
 
     python bench.py                      # 1 GPU, 65,536 envs, defaults finish in < 2 min
+    python bench.py --gpus N             # starts N ranks itself (a child `python -m torch.distributed.run`, before any GPU call),
+                                         # relays rank 0's JSON line and exits with the child's code
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W      # one rank per GPU, envs sharded by index (weak scaling)
+           bench.py --gpus N --steps K --warmup W      # the same ranks started by the caller: one per GPU, envs sharded by index (weak scaling)
 
 A "step" is one pass of the hot path over one batch: ONE launch of the fused step kernel over the rank's 65,536 envs
 (rendezvous_env.py:160-221 + auto-reset :223-270), with the float32 action batch already resident in HBM
@@ -54,7 +56,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of the all-core CPU sample")
     ap.add_argument("--no-policy", action="store_true", help="skip the informational MLP-policy rollout leg")
     ap.add_argument("--no-large-n", action="store_true", help="skip the 4,194,304-env leg (fused layout beyond the Infinity Cache)")
-    ap.add_argument("--no-gather", action="store_true", help="N>1: skip timing the RCCL gather of rollouts to rank 0")
+    ap.add_argument("--no-gather", action="store_true", help="under torch.distributed: skip timing the RCCL gathers of rollouts to rank 0")
+    ap.add_argument("--gather-steps", type=int, default=64, help="steps per rollout of the per-rollout gather leg (one message per rank per rollout)")
+    ap.add_argument("--quick", action="store_true", help="the headline leg only (= --no-cpu-baseline --no-policy --no-large-n)")
     # rehearsal of the N>1 path on a box with ONE GPU (not a measurement): all ranks on cuda:0, collectives over gloo on the host
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl")
     ap.add_argument("--shared-gpu", action="store_true", help="rehearsal only: every rank uses cuda:0")
@@ -101,26 +105,64 @@ def cpu_baseline(n, seconds):
                                                 "cannot travel to the GPU box, so this figure is quoted from BASELINE.md section 2, not measured in this run"}}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (this process
+    has made no GPU call — torch is not even imported yet — and never replaces itself), pass its stderr through, relay rank 0's
+    JSON line on stdout and exit with the child's return code."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("[bench] starting " + " ".join(cmd[1:7]) + " ...", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            sys.stdout.write(line); sys.stdout.flush(); lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"[bench] the ranks exited 0 but printed {lines} result lines", file=sys.stderr)
+        rc = 1
+    sys.exit(rc)
+
+
 def main():
     args = parse()
+    if args.quick:
+        args.no_cpu_baseline = args.no_policy = args.no_large_n = True
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not under_launcher:
+        spawn_ranks(args)          # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N ...`")
-        args.gpus = world
+    args.gpus = world
     import torch
     import torch.distributed as dist
     from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
 
+    if not args.shared_gpu and torch.cuda.device_count() < world:      # (counting devices initialises nothing)
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs, this node shows {torch.cuda.device_count()} "
+                 "(--shared-gpu --backend gloo rehearses the multi-rank path on one GPU; it is not a measurement)")
+    if args.shared_gpu and args.backend == "nccl" and world > 1:
+        sys.exit("bench.py: RCCL refuses two ranks on one device; use --shared-gpu together with --backend gloo")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
     dev_index = 0 if args.shared_gpu else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     coll_device = device if args.backend == "nccl" else torch.device("cpu")   # where collective payloads live
-    if world > 1:
+    distributed = under_launcher       # a process group exists whenever a launcher started us, also at world size 1
+    if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)       # RCCL over xGMI
@@ -176,7 +218,7 @@ def main():
     p0 = time.perf_counter(); run_replay(); torch.cuda.synchronize()
     probe = max(time.perf_counter() - p0, 1e-6)
     reps = (-(-args.repeats // M)) if args.repeats > 0 else int(min(2000, max(5, -(-0.05 // probe))))
-    if world > 1:
+    if distributed:
         rr = torch.tensor([reps], dtype=torch.int64, device=coll_device)
         dist.all_reduce(rr, op=dist.ReduceOp.MAX)
         reps = int(rr.item())
@@ -185,7 +227,7 @@ def main():
     stats0 = env.get_stats(reset=True)
     del stats0
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-    if world > 1:
+    if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -195,30 +237,87 @@ def main():
         marks[r + 1].record()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if distributed:
         dist.barrier()
     region_ms = sorted(marks[r].elapsed_time(marks[r + 1]) / M for r in range(reps))
     elapsed = region_ms[reps // 2] * 1e-3                    # median K-step region, seconds (device time on the launch stream)
     spread = (region_ms[0] * 1e-3, region_ms[-1] * 1e-3)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    per_rank_us = [elapsed / K * 1e6]
+    if distributed:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        table = torch.zeros((world,), dtype=torch.float64, device=coll_device)
+        dist.all_gather_into_tensor(table, mine)
+        per_rank_us = [float(x) / K * 1e6 for x in table.cpu()]
+        elapsed = float(table.max().item())            # the MAX over ranks is what the job took
     launch_us = elapsed / K * 1e6
     stats = env.get_stats()
     assert stats["env_steps"] == n * K * R, (stats["env_steps"], n * K * R)   # exactly R x K launches over n envs were executed
+    global_stats = stats
+    if distributed:
+        from reinforcement_learning_rendezvous_amd.sharding import reduce_stats
+        global_stats = reduce_stats(stats, device=coll_device)      # one 96-byte all-gather
+        assert global_stats["env_steps"] == n * K * R * world
 
-    # ---- N>1: RCCL gather of one step's rollout (obs | reward | done packed into one [n,19] message per rank) to rank 0, timed separately
-    gather_ms = None
-    if world > 1 and not args.no_gather:
-        from reinforcement_learning_rendezvous_amd.sharding import RolloutGather
+    # ---- under torch.distributed: the two gathers to rank 0, timed separately from the step (never inside `value`).
+    #   per rollout: ONE message per rank per rdv_rollout launch (obs | actions | reward | log_prob | done | last_obs, written in place by
+    #                the kernel: sharding.RolloutBufferGather) — the single-learner flow of main.py:114;
+    #   per step   : ONE message per rank per rdv_step (obs | reward | done, written in place: sharding.RolloutGather.bind).
+    gather_info = None
+    if distributed and not args.no_gather:
+        from reinforcement_learning_rendezvous_amd.sharding import RolloutBufferGather, RolloutGather
+        from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+        on_dev = coll_device.type == "cuda"
+        npz = os.path.join(ROOT, "tests", "golden", "mlp_policy.npz")
+        pol_g = (MlpPolicy.from_npz(npz) if os.path.exists(npz) else MlpPolicy()).to(device)
+        pol_g.backend = "hip"
+        Tg = args.gather_steps
+        rbg = RolloutBufferGather(Tg, n, coll_device)
+        bufs = rbg.local if on_dev else None
+
+        def one_rollout():
+            nonlocal bufs
+            bufs = env.rollout(pol_g, Tg, out=bufs)
+            if not on_dev:                         # gloo rehearsal: the message lives on the host
+                for k_, v_ in rbg.local.items():
+                    v_.copy_(bufs[k_])
+        env.reset()
+        one_rollout(); rbg.gather()
+        torch.cuda.synchronize(); dist.barrier()
+        reps_g = 3 if not on_dev else 10
+        ev_r = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        t_roll = t_gath = 0.0
+        for _ in range(reps_g):
+            ev_r[0].record(); one_rollout(); ev_r[1].record(); torch.cuda.synchronize()
+            t_roll += ev_r[0].elapsed_time(ev_r[1])
+            dist.barrier(); g0 = time.perf_counter()
+            rbg.gather()
+            torch.cuda.synchronize(); dist.barrier()
+            t_gath += (time.perf_counter() - g0) * 1e3
+        rollout_ms, gather_rollout_ms = t_roll / reps_g, t_gath / reps_g
+        del bufs
+        # per step: the env's outputs ARE the message
         rg = RolloutGather(n, coll_device)
+        if on_dev:
+            rg.bind(env)
         for it in range(25):
             if it == 5:
                 torch.cuda.synchronize(); dist.barrier(); g0 = time.perf_counter()
-            rg.gather(env.obs.to(coll_device), env.reward.to(coll_device), env.done.to(coll_device))
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - g0) / 20 * 1e3
+            if on_dev:
+                rg.gather()
+            else:
+                rg.gather(env.obs.cpu(), env.reward.cpu(), env.done.cpu())
+        torch.cuda.synchronize(); dist.barrier()
+        gather_step_ms = (time.perf_counter() - g0) / 20 * 1e3
+        gather_info = {"rccl_gather_to_rank0_ms": gather_step_ms,
+                       "rccl_gather_message": f"per step: one planar obs|reward|done message per rank ({rg.message_bytes / 1e6:.2f} MB), written in place by rdv_step",
+                       "rccl_gather_rollout_ms": gather_rollout_ms, "rccl_gather_rollout_steps": Tg,
+                       "rccl_gather_rollout_message_bytes": rbg.message_bytes,
+                       "rccl_gather_rollout_expected_xgmi_ms": rbg.expected_xgmi_ms,
+                       "rccl_gather_rollout_launch_ms": rollout_ms,
+                       "rccl_gather_rollout_note": "one message per rank per rdv_rollout launch (obs|actions|reward|log_prob|done|last_obs = 101 B per "
+                                                   "env-step, written in place by the kernel); expected = bytes / one 153 GB/s xGMI link (peers send "
+                                                   "concurrently, each on its own link)" + ("" if on_dev else "; gloo rehearsal through host memory: NOT an xGMI measurement")}
+        pol_g.close()
 
     out = None
     if rank == 0:
@@ -260,11 +359,12 @@ def main():
                          "note": "achieved = 293 B x envs per launch / launch_us.  At 65,536 envs the 15 MB working set stays in the 256 MiB "
                                  "Infinity Cache between launches (FETCH/WRITE_SIZE count fabric requests, MALL hits included): the HBM "
                                  "fraction is notional at this size; large_n below is the same metric beyond that cache"},
-            "episodes_finished": stats["episodes"],
+            "episodes_finished": global_stats["episodes"],
+            "per_rank": {"launch_us": per_rank_us, "max_over_ranks_us": launch_us, "backend": args.backend if distributed else None,
+                         "process_group": bool(distributed)},
         }
-        if gather_ms is not None:
-            out["rccl_gather_to_rank0_ms"] = gather_ms
-            out["rccl_gather_message"] = f"one packed [n,19] float32 message per rank ({n * 19 * 4 / 1e6:.2f} MB) into a view of one [{world}*n,19] buffer"
+        if gather_info is not None:
+            out.update(gather_info)
 
     def timed_steps(e, acts, steps, reps):
         """median us per launch of `steps` graph-replayed rdv_step launches over `reps` replays (HIP events)"""
@@ -485,7 +585,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     env.close()
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -51,9 +51,10 @@ class RendezvousBatch:
                                      C.byref(self._h)))
         N.check(self._lib.rdv_set_kernel_variant(self._h, _VARIANT[variant]))
         n, dev = self.num_envs, self.device
-        self.obs = self._alloc("obs", (n, N.OBS_DIM), torch.float32)
-        self.reward = self._alloc("reward", (n,), torch.float32)
-        self.done = self._alloc("done", (n,), torch.uint8)
+        self._pending = None      # (source tensors) of a step_many / rollout whose last rows have not been copied into obs / reward / done yet
+        self._obs = self._alloc("obs", (n, N.OBS_DIM), torch.float32)
+        self._reward = self._alloc("reward", (n,), torch.float32)
+        self._done = self._alloc("done", (n,), torch.uint8)
         self.terminal_obs = self._alloc("terminal_obs", (n, N.OBS_DIM), torch.float32)
         self.episode_return = self._alloc("episode_return", (n,), torch.float32)
         self.episode_length = self._alloc("episode_length", (n,), torch.int32)
@@ -70,6 +71,53 @@ class RendezvousBatch:
     def _alloc(self, name, shape, dtype):
         """Device buffers of the batch (zero-filled); one place, so that a caller with its own arena can override it."""
         return torch.zeros(shape, dtype=dtype, device=self.device)
+
+    def bind_outputs(self, **tensors):
+        """Make caller-owned tensors the step outputs of the batch (``obs`` [N,17] f32, ``reward`` [N] f32, ``done`` [N] u8,
+        ``terminal_obs``, ``episode_return``, ``episode_length``, ``done_reason``): ``rdv_step`` then writes them in place — e.g.
+        views of a gather message (sharding.RolloutGather.bind) or of a caller's arena.  The current contents are carried over."""
+        spec = {"obs": ((self.num_envs, N.OBS_DIM), torch.float32), "reward": ((self.num_envs,), torch.float32),
+                "done": ((self.num_envs,), torch.uint8), "terminal_obs": ((self.num_envs, N.OBS_DIM), torch.float32),
+                "episode_return": ((self.num_envs,), torch.float32), "episode_length": ((self.num_envs,), torch.int32),
+                "done_reason": ((self.num_envs,), torch.uint8)}
+        for name, t in tensors.items():
+            if name not in spec:
+                raise TypeError(f"bind_outputs: unknown output {name!r}")
+            self._check_tensor(t, *spec[name], name)
+            if name == "obs" and t.data_ptr() % 16:
+                raise ValueError("bind_outputs: obs must be 16-byte aligned")
+            t.copy_(getattr(self, name))
+            setattr(self, "_" + name if name in ("obs", "reward", "done") else name, t)
+        self._out = N.StepOut(self.obs.data_ptr(), self.reward.data_ptr(), self.done.data_ptr(),
+                              self.terminal_obs.data_ptr(), self.episode_return.data_ptr(),
+                              self.episode_length.data_ptr(), self.done_reason.data_ptr(), None, None)
+        self._outs = {}
+
+    # obs / reward / done: the batch's current observation, last rewards and dones.  rdv_step writes them; the persistent launches
+    # (step_many, rollout) write their own [K,N,...] buffers instead, and the last rows are copied over only when somebody asks —
+    # a timed loop of persistent launches carries no extra copy kernels.
+    def _sync(self):
+        src, self._pending = self._pending, None
+        for name, t in src.items():
+            getattr(self, "_" + name).copy_(t)
+
+    @property
+    def obs(self):
+        if self._pending is not None:
+            self._sync()
+        return self._obs
+
+    @property
+    def reward(self):
+        if self._pending is not None:
+            self._sync()
+        return self._reward
+
+    @property
+    def done(self):
+        if self._pending is not None:
+            self._sync()
+        return self._done
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -124,8 +172,9 @@ class RendezvousBatch:
             base = [getattr(self._out, f) for f, _ in N.StepOut._fields_[:-2]]
             out = N.StepOut(*base, self.diag.data_ptr() if diag else None, self.eval.data_ptr() if accumulate else None)
             self._outs[key] = out
+        self._pending = None     # this launch rewrites all three
         N.check(self._lib.rdv_step(self._h, actions.data_ptr(), C.byref(out), self._stream()))
-        return self.obs, self.reward, self.done
+        return self._obs, self._reward, self._done
 
     # ------------------------------------------------------------------------------------------------ evaluation on the device
     def eval_begin(self):
@@ -162,7 +211,7 @@ class RendezvousBatch:
         so = N.StepOut(out["obs"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(), None, None, None,
                        out["done_reason"].data_ptr(), None, None)
         N.check(self._lib.rdv_step_many(self._h, actions.data_ptr(), K, C.byref(so), self._stream()))
-        self.obs.copy_(out["obs"][K - 1]); self.reward.copy_(out["reward"][K - 1]); self.done.copy_(out["done"][K - 1])
+        self._pending = dict(obs=out["obs"][K - 1], reward=out["reward"][K - 1], done=out["done"][K - 1])   # copied on first access
         return out
 
     def act(self, policy, deterministic=False, out=None):
@@ -190,7 +239,8 @@ class RendezvousBatch:
         N.check(self._lib.rdv_rollout(self._h, policy._hip_handle(dev), T, C.byref(ro), int(bool(deterministic)),
                                       C.c_uint64(policy.noise_seed), C.c_uint64(policy._calls), self._stream()))
         policy._calls += T
-        self.obs.copy_(out["last_obs"])      # the batch's current observation, as after step()
+        # the batch's current observation / last rewards / dones, as after step(): copied on first access
+        self._pending = dict(obs=out["last_obs"], reward=out["reward"][T - 1], done=out["done"][T - 1])
         return out
 
     # ------------------------------------------------------------------------------------------------ evaluator helpers

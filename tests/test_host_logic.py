@@ -164,6 +164,20 @@ def _free_port():
     return port
 
 
+def _cpu_rollout(env, pol, T, out, t0):
+    """The closed loop of RendezvousBatch.rollout on the CPU engine (deterministic actor), writing SB3's rollout-buffer rows into
+    `out` in place — what rdv_rollout does with the views of a RolloutBufferGather message."""
+    obs = env.obs
+    for t in range(T):
+        out["obs"][t].copy_(obs)
+        a = pol.mean(obs)
+        out["actions"][t].copy_(a)
+        out["log_prob"][t].copy_(-0.5 * (a * a).sum(dim=1) + float(t0 + t))      # any per-row function: the gather must carry it
+        obs, rew, done = env.step(torch.clamp(a, -1.0, 1.0))
+        out["reward"][t].copy_(rew); out["done"][t].copy_(done.to(torch.uint8))
+    out["last_obs"].copy_(obs)
+
+
 def _worker(rank, world, port, n_global, steps, q):
     import torch.distributed as dist
     from reinforcement_learning_rendezvous_amd import sharding
@@ -174,18 +188,22 @@ def _worker(rank, world, port, n_global, steps, q):
         n, p, storage="f32", seed=21, env_id_offset=env_id_offset))
     obs = env.reset()
     trace = []
-    rg = sharding.RolloutGather(hi - lo, torch.device("cpu"))              # one packed [n,19] message per rank and step, buffers reused
+    rg = sharding.RolloutGather(hi - lo, torch.device("cpu"))              # one planar obs|reward|done message per rank and step, buffers reused
     for t in range(steps):
         a = torch.from_numpy(counter_actions(3, t, n_global)[lo:hi])        # actions keyed by GLOBAL env id
         obs, rew, done = env.step(a)
         if t % 2:
             g = rg.gather(obs, rew, done.to(torch.uint8))
-            g = None if g is None else [g[0], g[1], g[2].to(torch.uint8)]
+            if rank == 0:                                                    # views [W, n, ...] of the one receive buffer
+                assert g[0].shape == (world, hi - lo, 17) and g[0].untyped_storage().data_ptr() == rg.full.untyped_storage().data_ptr()
+                g = [g[0].reshape(-1, 17), g[1].reshape(-1), g[2].reshape(-1)]
         else:
             g = sharding.gather_rollout([obs, rew, done.to(torch.uint8)])
         if rank == 0:
-            assert g[0].shape == (n_global, 17) and g[0].is_contiguous() is False and g[0].untyped_storage().data_ptr() == g[1].untyped_storage().data_ptr()
+            assert g[0].shape == (n_global, 17) and g[1].shape == (n_global,) and g[2].dtype == torch.uint8
             trace.append([x.numpy().copy() for x in g])
+    if rank == 0:                                                            # the received rows are views of ONE buffer: no concatenation
+        assert rg.gathered["obs"].untyped_storage().data_ptr() == rg.full.untyped_storage().data_ptr() == rg.gathered["done"].untyped_storage().data_ptr()
     try:                                                                     # shards of different sizes cannot be gathered: refused, not hung
         sharding.RolloutGather(hi - lo + rank, torch.device("cpu"))
         unequal_refused = False
@@ -194,8 +212,23 @@ def _worker(rank, world, port, n_global, steps, q):
     assert unequal_refused
     total = sharding.reduce_stats(env.get_stats())
     cols = sharding.gather_columns({"lo": np.full(hi - lo, lo), "ret": env.get_aux()[:, 6].numpy()})
+    # ---- per-rollout gather: T steps of the closed loop written INTO the message, one dist.gather per rollout
+    T = 5
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    rbg = sharding.RolloutBufferGather(T, hi - lo, torch.device("cpu"))
+    assert rbg.message_bytes >= T * (hi - lo) * 101 and all(v.untyped_storage().data_ptr() == rbg.msg.flat.untyped_storage().data_ptr() for v in rbg.local.values())
+    rollouts = []
+    for r in range(2):
+        _cpu_rollout(env, pol, T, rbg.local, r * T)
+        g = rbg.gather()
+        if rank == 0:
+            assert g["obs"].shape == (world, T, hi - lo, 17) and g["done"].dtype == torch.uint8
+            assert g["obs"].untyped_storage().data_ptr() == rbg.full.untyped_storage().data_ptr()
+            tm = sharding.RolloutBufferGather.as_time_major(g)
+            assert tm["obs"].shape == (T, n_global, 17) and tm["last_obs"].shape == (n_global, 17)
+            rollouts.append({k: v.numpy().copy() for k, v in tm.items()})
     if rank == 0:
-        q.put((trace, total, cols))
+        q.put((trace, total, cols, rollouts))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -204,12 +237,17 @@ def test_two_rank_sharding_equals_single_process():
     import torch.multiprocessing as tmp
     n, steps, world = 96, 48, 2
     ctx = tmp.get_context("spawn")
-    q = ctx.SimpleQueue()
+    q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
     for pr in procs:
         pr.start()
-    trace, total, cols = q.get()
+    try:
+        trace, total, cols, rollouts = q.get(timeout=240)      # a rank that raised never answers: fail, do not hang
+    except Exception:
+        for pr in procs:
+            pr.kill()
+        raise AssertionError(f"no result from rank 0 (exit codes {[pr.exitcode for pr in procs]})")
     for pr in procs:
         pr.join(timeout=120)
         assert pr.exitcode == 0
@@ -227,6 +265,20 @@ def test_two_rank_sharding_equals_single_process():
     assert ref["episodes"] > 50
     np.testing.assert_array_equal(cols["lo"], np.repeat([0, 48], 48))
     np.testing.assert_allclose(cols["ret"], single.get_aux()[:, 6].numpy(), rtol=0, atol=0)
+    # the gathered rollouts equal the single-process concatenation: the same closed loop on the undivided batch
+    torch.set_num_threads(1)
+    pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    T = 5
+    for r, got in enumerate(rollouts):
+        want = dict(obs=torch.zeros(T, n, 17), actions=torch.zeros(T, n, 6), reward=torch.zeros(T, n), log_prob=torch.zeros(T, n),
+                    done=torch.zeros(T, n, dtype=torch.uint8), last_obs=torch.zeros(n, 17))
+        _cpu_rollout(single, pol, T, want, r * T)
+        for k in want:
+            if k in ("obs", "last_obs", "reward", "done"):
+                np.testing.assert_array_equal(got[k], want[k].numpy(), err_msg=f"rollout {r}: {k}")
+            else:   # the actor's GEMM over 48 rows (a shard) vs 96 rows (the whole batch): last-bit differences of the mean
+                np.testing.assert_allclose(got[k], want[k].numpy(), rtol=0, atol=5e-6, err_msg=f"rollout {r}: {k}")
+    assert sum(int(g["done"].sum()) for g in rollouts) >= 0
 
 
 # ---------------------------------------------------------------------------------------------- evaluation (f-3)
