@@ -350,7 +350,8 @@ __device__ __forceinline__ void integrate_attitude_rk45(double* q, double* w, co
 // kLazy (training kernels): the velocity / rotation-rate errors are only ever compared after the position error has
 // passed its limit (:417 np.all, :348), and the corridor angle only inside the KOZ sphere (:397); far from the target
 // they are skipped and set to +inf, which fails exactly the comparisons the reference would fail.
-__device__ __forceinline__ void derive_chaser(const DevParams& P, const Env& e, Derived& d, double* Rc, double& inv_dist) {
+__device__ __forceinline__ void derive_chaser(const DevParams& P, const Env& e, Derived& d, double& inv_dist) {
+  double Rc[9];
   quat2mat(e.qc, Rc);
   double cap_l[3];
   matvec(Rc, P.capture_axis, cap_l);    // :431
@@ -360,8 +361,12 @@ __device__ __forceinline__ void derive_chaser(const DevParams& P, const Env& e, 
   // general.py:179: round(cos, 5) == rint(cos*1e5)/1e5; rotations preserve |capture_axis|, |corridor_axis|
   d.k_att = rint(-dot3(e.rc, cap_l) * (inv_dist * P.inv_capture_norm) * 1e5);           // :432
 }
+// (R(qc) is rebuilt inside the one branch that needs it, from the same canonical quaternion — the same matrix, bit for bit: carried
+//  over from derive_chaser it occupied 18 registers across the target's attitude step and the whole of this function, which is where
+//  the fused kernels' register pressure peaked: tools/vgpr_pressure.py.  The quaternion is passed through an empty asm there so that
+//  the compiler does not recognise the expression as the one derive_chaser evaluated and keep that result alive instead.)
 template <bool kLazy>
-__device__ __forceinline__ void derive_target(const DevParams& P, const Env& e, Derived& d, const double* Rc, double inv_dist) {
+__device__ __forceinline__ void derive_target(const DevParams& P, const Env& e, Derived& d, double inv_dist) {
   double Rt[9];
   quat2mat(e.qt, Rt);
   double rd_l[3];
@@ -370,28 +375,34 @@ __device__ __forceinline__ void derive_target(const DevParams& P, const Env& e, 
   d.pos2 = sumsq3(dp);                  // :463
   const double inf = __builtin_huge_val();
   d.vel2 = inf; d.rot2 = inf; d.k_corr = inf;
-  if (!kLazy || d.pos2 <= P.le2_rd) {
-    double wc_l[3], wt_l[3];
-    matvec(Rc, e.wc, wc_l);             // :458
-    matvec(Rt, e.wt, wt_l);             // :459
-    const double vd_l[3] = {fma(wt_l[1], rd_l[2], -wt_l[2] * rd_l[1]), fma(wt_l[2], rd_l[0], -wt_l[0] * rd_l[2]),
-                            fma(wt_l[0], rd_l[1], -wt_l[1] * rd_l[0])};                 // :461
-    const double dv[3] = {e.vc[0] - vd_l[0], e.vc[1] - vd_l[1], e.vc[2] - vd_l[2]};
-    const double dw[3] = {wc_l[0] - wt_l[0], wc_l[1] - wt_l[1], wc_l[2] - wt_l[2]};
-    d.vel2 = sumsq3(dv);                // :464
-    d.rot2 = sumsq3(dw);                // :466
-  }
+  // the corridor angle first: after it only the next branch needs R(qt), and that one is done with it before it builds R(qc)
   if (!kLazy || d.r2 <= P.lt2_koz) {
     double corr_l[3];
     matvec(Rt, P.corridor_axis, corr_l);                                                // :400
     d.k_corr = rint(dot3(e.rc, corr_l) * (inv_dist * P.inv_corridor_norm) * 1e5);
   }
+  if (!kLazy || d.pos2 <= P.le2_rd) {
+    double wt_l[3];
+    matvec(Rt, e.wt, wt_l);             // :459
+    const double vd_l[3] = {fma(wt_l[1], rd_l[2], -wt_l[2] * rd_l[1]), fma(wt_l[2], rd_l[0], -wt_l[0] * rd_l[2]),
+                            fma(wt_l[0], rd_l[1], -wt_l[1] * rd_l[0])};                 // :461
+    const double dv[3] = {e.vc[0] - vd_l[0], e.vc[1] - vd_l[1], e.vc[2] - vd_l[2]};
+    d.vel2 = sumsq3(dv);                // :464
+    // R(qc) only now (the asm also takes the target-side results as inputs, which orders it behind them: one matrix alive at a time)
+    double Rc[9], wc_l[3];
+    double qc_again[4] = {e.qc[0], e.qc[1], e.qc[2], e.qc[3]};
+    asm volatile("" : "+v"(qc_again[0]), "+v"(qc_again[1]), "+v"(qc_again[2]), "+v"(qc_again[3]), "+v"(wt_l[0]), "+v"(wt_l[1]), "+v"(wt_l[2]), "+v"(d.vel2));
+    quat2mat(qc_again, Rc);
+    matvec(Rc, e.wc, wc_l);             // :458
+    const double dw[3] = {wc_l[0] - wt_l[0], wc_l[1] - wt_l[1], wc_l[2] - wt_l[2]};
+    d.rot2 = sumsq3(dw);                // :466
+  }
 }
 template <bool kLazy>
 __device__ __forceinline__ void derive(const DevParams& P, const Env& e, Derived& d) {
-  double Rc[9], inv_dist;
-  derive_chaser(P, e, d, Rc, inv_dist);
-  derive_target<kLazy>(P, e, d, Rc, inv_dist);
+  double inv_dist;
+  derive_chaser(P, e, d, inv_dist);
+  derive_target<kLazy>(P, e, d, inv_dist);
 }
 
 // k / 1e5 correctly rounded (k is an integer-valued double, |k| <= 1e5): product by 1e-5 plus one residual correction
@@ -455,19 +466,30 @@ __device__ __forceinline__ float normalized(double val, double lo, double span, 
   q = fma(fma(-q, span, y), inv_span, q);
   return (float)(q + -1.0);
 }
-// get_observation (:294-311)
-__device__ __forceinline__ void observation(const DevParams& P, const Env& e, float* o) {
+// get_observation (:294-311).  The 17 floats are handed to `sink(j, value)` one by one as they are formed — a kernel whose sink writes
+// the env's staged row in LDS never holds the observation in registers (as an array it was live from here to the row store, across
+// done / reward / statistics: 17 of the step kernels' registers).
+template <typename Sink>
+__device__ __forceinline__ void observation_to(const DevParams& P, const Env& e, Sink&& sink) {
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[i] = normalized(e.rc[i], P.obs_lo_r, P.obs_span_r, P.obs_inv_span_r);
+  for (int i = 0; i < 3; ++i) sink(i, normalized(e.rc[i], P.obs_lo_r, P.obs_span_r, P.obs_inv_span_r));
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[3 + i] = normalized(e.vc[i], P.obs_lo_v, P.obs_span_v, P.obs_inv_span_v);
+  for (int i = 0; i < 3; ++i) sink(3 + i, normalized(e.vc[i], P.obs_lo_v, P.obs_span_v, P.obs_inv_span_v));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[6 + i] = (float)e.qc[i];
+  for (int i = 0; i < 4; ++i) sink(6 + i, (float)e.qc[i]);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) o[10 + i] = normalized(e.wc[i], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w);
+  for (int i = 0; i < 3; ++i) sink(10 + i, normalized(e.wc[i], P.obs_lo_w, P.obs_span_w, P.obs_inv_span_w));
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[13 + i] = (float)e.qt[i];
+  for (int i = 0; i < 4; ++i) sink(13 + i, (float)e.qt[i]);
 }
+__device__ __forceinline__ void observation(const DevParams& P, const Env& e, float* o) {
+  observation_to(P, e, [&](int j, float v) { o[j] = v; });
+}
+// the sink of a row of floats in memory (LDS staging rows, slots): element j of the observation -> row[j]
+struct RowSink {
+  float* row;
+  __device__ __forceinline__ void operator()(int j, float v) const { row[j] = v; }
+};
 
 // ---------------------------------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al., SC'11), counter = (env id lo, env id hi, episode, block), key = seed.
@@ -645,8 +667,7 @@ __device__ __forceinline__ void reset_env(const DevParams& P, Env& e, uint64_t s
   reset_aux<ST>(P, e);
 }
 
-struct StepResult {
-  float obs[17];
+struct StepResult {   // (the observation goes to the caller's sink: see observation_to)
   float reward;
   double reward64;   // the reward before its float32 store (the reference's evaluators sum the float64 value, monte_carlo.py:150)
   int done;      // 0/1
@@ -654,9 +675,13 @@ struct StepResult {
 };
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
-template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false>
-__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d) {
+template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink>
+__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink) {
   const ST tag = ST(0);
+  // :201-202, :333 need the action only through these two float32 sums: formed here, so that the six action registers die with the
+  // impulses below instead of living to the end of the transition
+  const float sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
+  const float sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
   double Rc0[9];
   quat2mat(e.qc, Rc0);
@@ -684,8 +709,8 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   for (int i = 0; i < 3; ++i) e.wc[i] = canon(e.wc[i], tag);
 #pragma unroll
   for (int i = 0; i < 4; ++i) e.qc[i] = canon(e.qc[i], tag);
-  double Rc[9], inv_dist;
-  derive_chaser(P, e, d, Rc, inv_dist);
+  double inv_dist;
+  derive_chaser(P, e, d, inv_dist);
   const double att = attitude_error_of(P, d.k_att);
   // target side (:184)
   if (kGeneral) {
@@ -697,7 +722,7 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) e.qt[i] = canon(e.qt[i], tag);
-  derive_target<kLazy>(P, e, d, Rc, inv_dist);
+  derive_target<kLazy>(P, e, d, inv_dist);
   const bool inst_coll = in_koz(P, d);
   // :187-190
   if (!(e.flags & FLAG_COLLIDED)) {
@@ -707,25 +732,11 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   e.k += 1;                                                           // :193 t = round(k*dt, 3)
   e.bubble = canon(fmax(e.bubble - P.bubble_decrease_rate, P.bubble_min), tag);   // :196-198
   // :201-202; float32 sums, see the promotion table in oracle/rdv_oracle.c
-  const float sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
-  const float sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
   e.sum_dv = (double)((float)e.sum_dv + mul_f32_rn(sum_v, P.max_delta_v_f32));
   e.sum_dw = canon(fma((double)sum_w, P.max_delta_w, e.sum_dw), tag);
 
-  observation(P, e, r.obs);                                           // :205
-  // :355-386
-  bool outside = false;
-#pragma unroll
-  for (int i = 0; i < 17; ++i) outside |= !(fabsf(r.obs[i]) <= 1.0f);                  // Box.contains; NaN -> outside
-  // norm(rc) > bubble_radius (:369): the bubble changes every step, so the sum of squares is compared with bubble^2 bracketed by its
-  // rounding, and the correctly rounded square root decides inside the bracket (one wave in ~10^14 goes there)
-  const double b2 = e.bubble * e.bubble;
-  bool c_bubble = d.r2 > b2 * (1.0 + 1e-15);
-  if (__builtin_expect(!c_bubble && d.r2 > b2 * (1.0 - 1e-15), 0)) c_bubble = sqrt(d.r2) > e.bubble;
-  const bool c_time = e.k >= P.k_time, c_att = d.k_att <= P.ka_done_max;
-  r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
-  r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
-  // :313-353
+  // :313-353 (the reward does not depend on the observation or on done: computed first, the observation last, so that its 17 floats
+  // go straight to the sink)
   double rew = P.att_term * fma(-att, P.inv_max_attitude_error, 1.0);                  // :329
   rew += (double)(mul_f32_rn(P.fuel_scale_f32, sum_v) / P.fuel_div_f32);               // :333
   if (inst_coll) rew -= P.coll_term;                                                   // :336-337
@@ -736,6 +747,20 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   e.ep_ret = canon(e.ep_ret + rew, tag);
   r.reward = (float)rew;
   r.reward64 = rew;
+  // :205, :355-386
+  bool outside = false;
+  observation_to(P, e, [&](int j, float v) {
+    outside |= !(fabsf(v) <= 1.0f);                                                    // Box.contains; NaN -> outside
+    sink(j, v);
+  });
+  // norm(rc) > bubble_radius (:369): the bubble changes every step, so the sum of squares is compared with bubble^2 bracketed by its
+  // rounding, and the correctly rounded square root decides inside the bracket (one wave in ~10^14 goes there)
+  const double b2 = e.bubble * e.bubble;
+  bool c_bubble = d.r2 > b2 * (1.0 + 1e-15);
+  if (__builtin_expect(!c_bubble && d.r2 > b2 * (1.0 - 1e-15), 0)) c_bubble = sqrt(d.r2) > e.bubble;
+  const bool c_time = e.k >= P.k_time, c_att = d.k_att <= P.ka_done_max;
+  r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
+  r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
 }
 
 // diagnostics row (RDV_DIAG_DIM = 8) — evaluator-only

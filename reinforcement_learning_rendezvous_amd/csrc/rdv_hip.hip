@@ -278,10 +278,11 @@ __device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, uint64
   }
 }
 
-// per-env outputs of a transition (coalesced 4-/1-byte stores; the sparse ones only where an episode ended)
+// per-env outputs of a transition (coalesced 4-/1-byte stores; the sparse ones only where an episode ended).  `row`: the lane's
+// staged observation row (LDS), which still holds the terminal observation here — read back by the ~5 % of lanes whose episode ended
 template <bool kTerminalObs>
 __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i, bool active, bool fin, const StepResult& r,
-                                                   const Env& e) {
+                                                   const Env& e, const float* row) {
   if (active) {
     A.reward[i] = r.reward;
     A.done[i] = (uint8_t)r.done;
@@ -293,29 +294,31 @@ __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i,
     if (kTerminalObs && A.terminal_obs) {
       float* t = A.terminal_obs + i * RDV_OBS_DIM;
 #pragma unroll
-      for (int j = 0; j < RDV_OBS_DIM; ++j) t[j] = r.obs[j];
+      for (int j = 0; j < RDV_OBS_DIM; ++j) t[j] = row[j];
     }
     if (A.episode_return) A.episode_return[i] = (float)e.ep_ret;
     if (A.episode_length) A.episode_length[i] = e.k;
   }
 }
 
-// step one lane's env (or report a halted one); returns whether a transition was executed
-template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false>
+// step one lane's env (or report a halted one); returns whether a transition was executed.  The observation goes to `sink(j, v)`
+// element by element (zeros for a lane without an env): see observation_to.
+template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false, typename Sink>
 __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, int64_t i, bool active, Env& e, const float* a,
-                                        StepResult& r) {
+                                        StepResult& r, Sink&& sink) {
   r.done = 0; r.reason = 0; r.reward = 0.0f; r.reward64 = 0.0;
-#pragma unroll
-  for (int j = 0; j < RDV_OBS_DIM; ++j) r.obs[j] = 0.0f;
   bool stepped = false;
-  if (active) {
+  if (!active) {
+#pragma unroll
+    for (int j = 0; j < RDV_OBS_DIM; ++j) sink(j, 0.0f);
+  } else {
     Derived d;
     if (e.flags & FLAG_HALTED) {
-      observation(P, e, r.obs);
+      observation_to(P, e, sink);
       r.done = 1;
       if (kDiag && A.diag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
     } else {
-      step_env<ST, !kDiag, kGeneral, kRaw>(P, e, a, r, d);
+      step_env<ST, !kDiag, kGeneral, kRaw>(P, e, a, r, d, sink);
       stepped = true;
       if (kDiag) {   // evaluator build only: keeps the training kernel short
         double dg[RDV_DIAG_DIM];
@@ -371,10 +374,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
   load_actions(A.actions, wave_base, lane, active, a);
 
   StepResult r;
-  const bool stepped = advance<ST, kDiag, kGeneral, kRaw>(A, P, i, active, e, a, r);
+  // observations: own row -> LDS as it is formed (stride 17: conflict-free) -> contiguous stores
+  const RowSink my_row{wl + lane * RDV_OBS_DIM};
+  const bool stepped = advance<ST, kDiag, kGeneral, kRaw>(A, P, i, active, e, a, r, my_row);
   const bool fin = stepped && r.done;
   stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-  store_step_outputs<true>(A, i, active, fin, r, e);
+  store_step_outputs<true>(A, i, active, fin, r, e, my_row.row);
   bool did_reset = false;
   if (fin) {
     if (A.on_done == RDV_ON_DONE_RESET) {
@@ -382,15 +387,12 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
       const double* row = nullptr;
       if (A.tape_depth > 0) row = A.tape + ((int64_t)(e.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
       reset_env<ST>(P, e, A.seed, A.env_id_offset + (uint64_t)i, row);
-      observation(P, e, r.obs);
+      observation_to(P, e, my_row);
       did_reset = true;
     } else if (A.on_done == RDV_ON_DONE_HALT) {
       e.flags |= FLAG_HALTED;
     }
   }
-  // observations: own row -> LDS (stride 17: conflict-free) -> contiguous stores
-#pragma unroll
-  for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
   wave_lds_fence();
   if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see kStreamRowsMaxEnvs
   else store_obs_rows<false>(A.obs, wave_base, rows, lane, wl);
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __rest
 // lone serial chain.  Same expressions on the same inputs: bit-identical results.  (Forced to 128 VGPRs for four waves per SIMD it
 // spills 16 dwords and loses: 342 against 315 us at 4.2 M envs.)
 template <typename ST>
-__global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(ST) == 4 ? 4 : 3))) void step_kernel_parts(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                              uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   StepArgs A = A_rest;
   A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
@@ -449,41 +451,49 @@ __global__ __launch_bounds__(kBlock) void step_kernel_parts(void* ws_hot, const 
   static_assert(kBlock == kGroupEnvs, "refill_pass_lds is written for 256-env workgroups");
   const DevParams& P = *Pp;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave_in_block = threadIdx.x >> 6;
+  // Everything that is the same for the 64 lanes of a wave is computed on the scalar unit (readfirstlane tells the compiler that the wave
+  // index is uniform): the wave's first env, its row count, the bases of its slices of every array.  A lane then addresses memory as
+  // [uniform base in SGPRs] + [32-bit lane offset] — as 64-bit per-lane indices these held ~10 vector registers for the whole kernel.
+  const int wave_in_block = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8); with A.xcd_per != 0 XCD x walks its own
   // contiguous eighth of the envs in ascending order instead of every 8th workgroup of the whole batch (see kXcdOrderMaxEnvs)
   const int64_t lblock = A.xcd_per ? (int64_t)(blockIdx.x & 7) * A.xcd_per + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
   const int64_t block_base = lblock * kBlock;
-  const int64_t i = block_base + threadIdx.x;
-  const int64_t wave_base = i - lane;
+  const int64_t wave_base = block_base + wave_in_block * kWave;
   const int64_t n = A.n;
-  const bool active = i < n;
-  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
+  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;    // valid envs of this wave (may be <= 0)
+  const bool active = lane < rows;
   float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
   V* ws = reinterpret_cast<V*>(A.ws);
   const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform: the barriers below are executed by all waves or by none
 
   {
+    V* wsw = ws + wave_base;                             // this wave's slice of every chunk array: chunk c of lane l at wsw[c * cs + l]
+    StepArgs Aw = A;                                     // ... and of the per-env outputs (null stays null)
+    Aw.reward = A.reward + wave_base; Aw.done = A.done + wave_base;
+    Aw.done_reason = A.done_reason ? A.done_reason + wave_base : nullptr;
+    Aw.terminal_obs = A.terminal_obs ? A.terminal_obs + wave_base * RDV_OBS_DIM : nullptr;
+    Aw.episode_return = A.episode_return ? A.episode_return + wave_base : nullptr;
+    Aw.episode_length = A.episode_length ? A.episode_length + wave_base : nullptr;
     Env e;
-    if (active) load_env<ST>(ws, A.cs, i, e);
+    if (active) load_env<ST>(wsw, A.cs, lane, e);
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
     const uint64_t slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;   // (a padding workgroup of the XCD order has no envs)
     float a[RDV_ACT_DIM];
-    load_actions(A.actions, wave_base, lane, active, a);
+    load_actions(A.actions + wave_base * RDV_ACT_DIM, 0, lane, active, a);
     StepResult r;
-    const bool stepped = advance<ST, false, false, false>(A, P, i, active, e, a, r);
+    const RowSink my_row{wl + lane * RDV_OBS_DIM};      // the observation is staged as it is formed
+    const bool stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row);
     const bool fin = stepped && r.done;
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-    store_step_outputs<true>(A, i, active, fin, r, e);
+    store_step_outputs<true>(Aw, lane, active, fin, r, e, my_row.row);
     const bool to_reset = fin && resets;
     if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-#pragma unroll
-    for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
     if (resets) {
       job_kind[threadIdx.x] = to_reset ? JOB_REFILL : JOB_NONE;
       job_counter[threadIdx.x] = e.episode;
     }
-    if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);   // a listed env's state is written by the parts, all seven chunks
+    if (stepped && !to_reset) store_env<ST>(wsw, A.cs, lane, e, false);   // a listed env's state is written by the parts, all seven chunks
   }
   if (resets) {
     __syncthreads();   // the workgroup's finished envs are listed, every observation row is staged
@@ -564,16 +574,18 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     float a[RDV_ACT_DIM];
     load_actions(A.actions, wave_base, lane, active, a);
     RDV_STAMP(1);
-    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r);
+    // observation rows: own row -> LDS as it is formed (stride 17: conflict-free) -> contiguous stores.  If an env of this wave
+    // resets, the rows stay in LDS: the service wave swaps in the reset observation and stores the block — which is why this kernel
+    // also keeps the row in registers: after the barrier the LDS row may already hold the next episode's observation when the terminal
+    // one is stored (one wave per SIMD here: the 17 registers cost no occupancy).
+    float obs_r[RDV_OBS_DIM];
+    float* my_row = wl + lane * RDV_OBS_DIM;
+    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; });
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     const bool to_reset = fin && resets;
     const unsigned long long m_reset = __ballot(to_reset);
     if (lane == 0) fin_mask[wv] = m_reset;
-    // observation rows: own row -> LDS (stride 17: conflict-free) -> contiguous stores.  If an env of this wave resets,
-    // the rows stay in LDS: the service wave swaps in the reset observation and stores the block.
-#pragma unroll
-    for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = r.obs[j];
     // The barrier comes HERE, as soon as the service waves have what they wait for (which envs ended, the observation rows), not at the
     // end of the step wave: the statistics, the per-env outputs and the stores of the step wave (~1.1 us) then run beside the service
     // waves' reset writes (~0.9 us) instead of in front of them (stamps: 5.7 -> ~5.0 us from the first wave's entry to the last exit).
@@ -581,7 +593,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     __syncthreads();
     RDV_STAMP(4);
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-    store_step_outputs<true>(A, i, active, fin, r, e);
+    store_step_outputs<true>(A, i, active, fin, r, e, obs_r);
     if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
     if (m_reset == 0ull) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
     RDV_STAMP(5);

@@ -300,7 +300,8 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #pragma unroll
       for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[sl * RDV_ACT_DIM + j] : 0.0f;
       StepResult r;
-      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, it, active, e, a, r);   // kRaw: a rollout may start from an injected state
+      float* my_row = obs_cur + sl * RDV_OBS_DIM;     // obs_{t+1} of this env: written as it is formed (the actor reads it after the barrier)
+      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, it, active, e, a, r, RowSink{my_row});   // kRaw: a rollout may start from an injected state
 #ifdef RDV_STAMPS
       __builtin_amdgcn_sched_barrier(0); te2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
         if (fin) {
           SlotRaw<ST> raw;
           slot_fetch<ST>(L, sl, raw);
-          slot_unpack<ST>(P, raw, e, r.obs);      // SB3: the first obs of the next episode
+          slot_unpack<ST>(P, raw, e, my_row);     // SB3: the first obs of the next episode
           slot_dirty = true; wt_dirty = true;
         }
         job_kind[sl] = fin ? JOB_REFILL : JOB_NONE;   // read by the refilling waves after the next barrier
@@ -327,8 +328,6 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       } else if (fin && A.on_done == RDV_ON_DONE_HALT) {
         e.flags |= FLAG_HALTED;
       }
-#pragma unroll
-      for (int j = 0; j < RDV_OBS_DIM; ++j) obs_cur[sl * RDV_OBS_DIM + j] = r.obs[j];
     }
     ROLL_T(te3);
     __syncthreads();   // observations of step t+1 are in LDS

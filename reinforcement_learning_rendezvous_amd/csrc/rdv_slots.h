@@ -120,7 +120,12 @@ __device__ __forceinline__ void slot_copy(const SlotStore<ST>& D, int64_t di, co
 }
 
 __device__ __forceinline__ const double* tape_row_of(const double* tape, int32_t depth, int64_t n, int64_t i, uint32_t counter) {
-  return depth > 0 ? tape + ((int64_t)(counter % (uint32_t)depth) * n + i) * RDV_STATE_DIM : nullptr;
+  if (depth <= 0) return nullptr;
+  // (the divisor passes through an empty asm: hoisted out of the callers' loops, the reciprocal of this test-only path's modulo cost a
+  //  vector register — and, at the fused kernel's 128-register budget, a scratch slot — on the path of every launch)
+  uint32_t dep = (uint32_t)depth;
+  asm volatile("" : "+s"(dep));
+  return tape + ((int64_t)(counter % dep) * n + i) * RDV_STATE_DIM;
 }
 
 // The whole reset for episode `counter` of env (global id `env_id`): state + bookkeeping + observation, one lane per env.

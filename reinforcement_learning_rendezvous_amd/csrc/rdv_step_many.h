@@ -114,7 +114,8 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
       for (int q = 0; q < 3; ++q) { a[2 * q] = pre[q].x; a[2 * q + 1] = pre[q].y; }
       if (k + 1 < K) fetch(k + 1, pre);
       StepResult r;
-      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, i, active, e, a, r);   // kRaw: the tape may start from an injected state
+      float* my_row = my_obs + lane * RDV_OBS_DIM;    // this env's staged observation row, written as it is formed
+      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, i, active, e, a, r, RowSink{my_row});   // kRaw: the tape may start from an injected state
       const bool fin = stepped && r.done;
       if (active) {
         const int64_t o = (int64_t)k * n + i;
@@ -131,15 +132,13 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
         if (take) {
           SlotRaw<ST> raw;
           slot_fetch<ST>(L, slot, raw);
-          slot_unpack<ST>(P, raw, e, r.obs);      // SB3: the first obs of the next episode
+          slot_unpack<ST>(P, raw, e, my_row);     // SB3: the first obs of the next episode
           slot_dirty = true; wt_dirty = true;
         }
         job_kind[slot] = take ? JOB_REFILL : JOB_NONE;
         job_counter[slot] = e.episode;
         __syncthreads();   // B: the slots taken in this step are listed
       }
-#pragma unroll
-      for (int j = 0; j < RDV_OBS_DIM; ++j) my_obs[lane * RDV_OBS_DIM + j] = r.obs[j];
       wave_lds_fence();
       store_obs_rows<true>(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs, vec_rows);   // written once: non-temporal
       wave_lds_fence();   // the rows are rewritten by the next step
