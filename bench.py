@@ -394,19 +394,44 @@ def main():
         vec.reset()
         for k_ in range(10):
             vec.step(a_np[k_ % 4])
+        # the slowest steps of this loop are the interpreter's garbage collector, not the boundary: every step allocates ~7,000 dicts
+        # (infos + their "episode" entries), so generation-0/1 collections run inside most steps and a generation-2 pass (which walks
+        # every live container, the 65,536 infos dicts included) lands in one step now and then.  The pauses are recorded beside the
+        # step times so that the line shows which is which.
+        import gc
+        pauses, t_gc = [], [0.0]
+
+        def on_gc(phase, info):
+            if phase == "start":
+                t_gc[0] = time.perf_counter()
+            else:
+                pauses.append((info["generation"], time.perf_counter() - t_gc[0], len(per)))
         per = []
+        gc.callbacks.append(on_gc)
         for k_ in range(200):
             p0 = time.perf_counter()
             vec.step(a_np[k_ % 4])
             per.append(time.perf_counter() - p0)
-        per.sort()
+        gc.callbacks.remove(on_gc)
+        gc_in_step = [0.0] * len(per)
+        for gen_, dur_, k_ in pauses:
+            if k_ < len(per):
+                gc_in_step[k_] += dur_
+        worst = max(range(len(per)), key=lambda k_: per[k_])
+        order = sorted(per)
         out["vecenv_numpy_boundary"] = {"value": n * len(per) / sum(per), "unit": "env steps/s", "steps": len(per),
-                                        "median_value": n / per[len(per) // 2],
-                                        "ms_per_step": {"mean": sum(per) / len(per) * 1e3, "median": per[len(per) // 2] * 1e3,
-                                                        "p90": per[int(len(per) * 0.9)] * 1e3, "max": per[-1] * 1e3},
+                                        "median_value": n / order[len(per) // 2],
+                                        "ms_per_step": {"mean": sum(per) / len(per) * 1e3, "median": order[len(per) // 2] * 1e3,
+                                                        "p90": order[int(len(per) * 0.9)] * 1e3, "p99": order[int(len(per) * 0.99)] * 1e3,
+                                                        "max": order[-1] * 1e3},
+                                        "gc": {"collections_by_generation": [sum(1 for g_, _, _ in pauses if g_ == j) for j in range(3)],
+                                               "longest_pause_ms": max([d_ for _, d_, _ in pauses], default=0.0) * 1e3,
+                                               "gc_ms_inside_the_slowest_step": gc_in_step[worst] * 1e3,
+                                               "slowest_step_ms": per[worst] * 1e3},
                                         "note": "RendezvousVecEnv.step with NumPy actions in, NumPy obs/reward/done + infos out (PCIe-inclusive; "
                                                 "never the bench value): one packed D2H message + the rows of the finished envs; ~70 % of it "
-                                                "is building the infos dicts of the ~3,500 finished envs per step (profiles/r02_vecenv_profile.txt)"}
+                                                "is building the infos dicts of the ~3,500 finished envs per step (profiles/r02_vecenv_profile.txt); "
+                                                "`gc` shows how much of the slowest step was the interpreter's garbage collector"}
         env.reset()
 
     # ---- the same metric with fp64 state storage (parity mode), N=1 only

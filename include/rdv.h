@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RDV_ABI_VERSION 2
+#define RDV_ABI_VERSION 3
 #define RDV_OBS_DIM 17    /* rendezvous_env.py:133-137 */
 #define RDV_ACT_DIM 6     /* rendezvous_env.py:140-144 */
 #define RDV_STATE_DIM 20  /* rc3 vc3 qc4 wc3 qt4 wt3, the column order of results/data_monte_carlo_initial_conditions.csv */
@@ -43,8 +43,18 @@ typedef enum RdvError {
   RDV_ERR_HIP = -3,            /* a HIP runtime call failed; see rdv_last_error() */
   RDV_ERR_OUT_OF_MEMORY = -4,
   RDV_ERR_BAD_HANDLE = -5,
-  RDV_ERR_BAD_PARAMS = -6      /* violates an assert of the reference ctor (rendezvous_env.py:148-156) */
+  RDV_ERR_BAD_PARAMS = -6,     /* violates an assert of the reference ctor (rendezvous_env.py:148-156) */
+  RDV_ERR_DEVICE_FAULT = -7    /* a kernel of this handle reported a fault in its device error word (RdvDeviceError); the handle's
+                                  results since then are not to be trusted.  Sticky: every later call on the handle returns it too */
 } RdvError;
+
+/* Bits of a handle's device error word: written by the kernels (atomic OR into a word of the workspace), read back by the calls
+ * that synchronise anyway (rdv_get_stats, rdv_eval_summary, rdv_restore).  Nothing a kernel detects is absorbed silently. */
+typedef enum RdvDeviceError {
+  RDV_DEVERR_LOST_SIGNAL = 1u  /* rdv_rollout: an env wave gave up waiting for the slot-refill signal of its workgroup (a bounded spin
+                                  in LDS, ~0.3 s): it went on with slots that may be stale, so rewards / observations after that point
+                                  may belong to the wrong episode */
+} RdvDeviceError;
 
 /* Precision in which the persistent per-env state is held in HBM.  Arithmetic is fp64 in both. */
 typedef enum RdvStorage {
@@ -150,6 +160,9 @@ typedef struct RdvEnvBatch* rdv_handle;
 
 int         rdv_version(void);
 const char* rdv_last_error(void);
+/* The RdvError a device error word stands for (RDV_OK for 0, RDV_ERR_DEVICE_FAULT otherwise) with the message rdv_last_error()
+ * then returns naming every bit that is set.  Host-only, needs no GPU: it is the check rdv_get_stats applies to the word it reads. */
+int         rdv_device_error_code(uint32_t device_error_word);
 
 /* Reference ctor defaults (rendezvous_env.py:52-126, :313). Host-only, needs no GPU. */
 int rdv_params_default(RdvParams* out_host);
@@ -229,8 +242,10 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out_host, voi
 /* n_steps calls of rdv_step for an OPEN-LOOP action tape actions [n_steps,N,6] in ONE persistent launch: the env state stays in
  * registers between the steps and there is no launch boundary (~4 us per step at 65,536 envs instead of ~7.8).  out->obs
  * [n_steps,N,17], out->reward [n_steps,N], out->done [n_steps,N] and (nullable) out->done_reason [n_steps,N] are written; the
- * other members of RdvStepOut must be NULL.  Same results, final state and statistics as the loop,
- * general rigid bodies (rdv_set_rigid_body) included. */
+ * other members of RdvStepOut must be NULL.  Same results, final state and statistics as the loop.
+ * General rigid bodies (rdv_set_rigid_body with a non-isotropic tensor, a torque, or RK45 asked for): the call runs that loop itself —
+ * n_steps launches of rdv_step on `stream` (the per-lane RK45 does not fit a persistent kernel's register budget without scratch,
+ * and such a step is bound by the integrator, not by launch boundaries). */
 int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const RdvStepOut* out_host, void* stream);
 
 /* Direct state access as monte_carlo.py:107-112 does (flags/aux are deliberately left untouched).
@@ -278,7 +293,8 @@ typedef struct RdvEvalSummary {
 int rdv_eval_begin(rdv_handle h, double* eval, void* stream);
 int rdv_eval_summary(rdv_handle h, const double* eval, RdvEvalSummary* out_host, void* stream);
 
-/* Copy the device statistics to the host (synchronises `stream`); reset != 0 zeroes them afterwards. */
+/* Copy the device statistics to the host (synchronises `stream`); reset != 0 zeroes them afterwards.  Also reads the handle's device
+ * error word: if a kernel set it, `out_host` is still filled and the call returns RDV_ERR_DEVICE_FAULT (sticky from then on). */
 int rdv_get_stats(rdv_handle h, RdvStats* out_host, int reset, void* stream);
 
 int64_t rdv_num_envs(rdv_handle h);
@@ -313,7 +329,8 @@ int rdv_policy_value(rdv_policy critic, const float* obs, float* values, int64_t
  * env time in) with the actor above, writing the rows SB3's RolloutBuffer.add receives.  Results are those of
  * rdv_policy_act(counter = noise_counter0 + t, env_id_offset = the handle's) followed by rdv_step, n_steps times; the env
  * state stays in registers and the observations / actions in LDS in between.  Episode statistics accumulate as in rdv_step.
- * General rigid bodies (rdv_set_rigid_body) are integrated inside the launch as rdv_step does.
+ * General rigid bodies (rdv_set_rigid_body with a non-isotropic tensor, a torque, or RK45 asked for): the call runs rdv_policy_act +
+ * rdv_step itself, n_steps times on `stream` (2 launches per step; the one-launch form spilled and was slower than this loop).
  */
 typedef struct RdvRolloutOut {
   float*   obs;        /* [T,N,17] required: the observation the actor saw at step t (buffer.observations) */

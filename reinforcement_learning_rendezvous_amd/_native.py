@@ -19,10 +19,11 @@ VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT, VARIANT_FUSED_INLANE = 0, 1, 2, 3
 OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM, EVAL_DIM = 17, 6, 20, 8, 8, 32
 
 ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVICE", -3: "RDV_ERR_HIP",
-               -4: "RDV_ERR_OUT_OF_MEMORY", -5: "RDV_ERR_BAD_HANDLE", -6: "RDV_ERR_BAD_PARAMS"}
+               -4: "RDV_ERR_OUT_OF_MEMORY", -5: "RDV_ERR_BAD_HANDLE", -6: "RDV_ERR_BAD_PARAMS", -7: "RDV_ERR_DEVICE_FAULT"}
+DEVERR_LOST_SIGNAL = 1
 
 # every symbol include/rdv.h declares (tests/test_abi.py checks the list against the header and the .so)
-SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
+SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_device_error_code", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
            "rdv_set_kernel_variant", "rdv_rigid_body_default", "rdv_set_rigid_body", "rdv_get_rigid_body",
            "rdv_reset", "rdv_step", "rdv_step_many", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_snapshot_bytes", "rdv_snapshot", "rdv_restore", "rdv_observe", "rdv_diagnose",
@@ -88,6 +89,7 @@ def build(force=False, quiet=True):
 
 
 _lib = None
+STRICT = True      # tools/lib_ab*.py load OLDER builds of the library for A/B timings and switch this off; the product never does
 
 
 def lib():
@@ -104,6 +106,7 @@ def lib():
     sig = {
         "rdv_version": (C.c_int, []),
         "rdv_last_error": (C.c_char_p, []),
+        "rdv_device_error_code": (C.c_int, [C.c_uint32]),
         "rdv_params_default": (C.c_int, [PP]),
         "rdv_params_validate": (C.c_int, [PP]),
         "rdv_workspace_bytes": (i64, [i64, C.c_int]),
@@ -140,7 +143,11 @@ def lib():
         "rdv_rollout": (C.c_int, [vp, vp, i32, C.POINTER(RolloutOut), C.c_int, u64, u64, vp]),
     }
     for name, (res, args) in sig.items():
-        fn = getattr(L, name)
+        fn = getattr(L, name, None)
+        if fn is None:
+            if STRICT:
+                raise RdvError(-2, f"{LIB_PATH} does not export {name}: it is not a build of this source tree (ABI {SYMBOLS and 3})")
+            continue
         fn.restype, fn.argtypes = res, args
     _lib = L
     return L

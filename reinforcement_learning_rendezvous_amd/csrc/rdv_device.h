@@ -542,15 +542,16 @@ __device__ __forceinline__ void reset_uniforms(uint64_t seed, uint64_t env_id, u
 // uniforms (only wc needs R(qc) and wt needs R(qt), :256, :258), so the preparation of a next-episode state can be shared out
 // over several waves, each running a short instruction stream over the same list of envs (prepared-state slots,
 // csrc/rdv_slots.h): the expressions — hence the results, bit for bit — are those of the whole reset.
-enum ResetPart : int { RESET_ALL = -1, RESET_RC_VC = 0, RESET_QC_WC = 1, RESET_QT = 2, RESET_WT = 3 };
+enum ResetPart : int { RESET_ALL = -1, RESET_RC_VC = 0, RESET_QC_WC = 1, RESET_QT = 2, RESET_WT = 3,
+                       RESET_CHASER = 4 /* rc, vc, qc, wc */, RESET_TARGET = 5 /* qt, wt */ };
 
 // reset (:223-262): the new state (the fields of kPart; the others are left untouched) from (seed, env id, e.episode) or from a
 // tape row.  Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
 template <typename ST, int kPart>
 __device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
   constexpr bool all = kPart == RESET_ALL;
-  constexpr bool do_rv = all || kPart == RESET_RC_VC, do_c = all || kPart == RESET_QC_WC, do_qt = all || kPart == RESET_QT || kPart == RESET_WT,
-                 do_wt = all || kPart == RESET_WT;
+  constexpr bool do_rv = all || kPart == RESET_RC_VC || kPart == RESET_CHASER, do_c = all || kPart == RESET_QC_WC || kPart == RESET_CHASER,
+                 do_qt = all || kPart == RESET_QT || kPart == RESET_WT || kPart == RESET_TARGET, do_wt = all || kPart == RESET_WT || kPart == RESET_TARGET;
   if (tape_row) {
     if (do_rv) {
 #pragma unroll

@@ -29,6 +29,12 @@
 
 namespace rdv {
 
+#ifndef RDV_PARTS_WAVES
+// amdgpu_waves_per_eu lower bound of step_kernel_parts<float>.  With 3 the allocator lands at 128 registers = FOUR waves per SIMD
+// without scratch; asked for 4 outright it squeezes to 126 and spills 3 dwords (tools/resource_table.py; tests/test_abi.py holds the
+// build to "<= 128 VGPRs, ScratchSize 0").  tools/lib_ab_large.py times the alternatives.
+#define RDV_PARTS_WAVES 3
+#endif
 constexpr int kBlock = 256;             // 4 waves per workgroup
 constexpr int kWave = 64;
 constexpr int kChunks = 7;
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __rest
 // lone serial chain.  Same expressions on the same inputs: bit-identical results.  (Forced to 128 VGPRs for four waves per SIMD it
 // spills 16 dwords and loses: 342 against 315 us at 4.2 M envs.)
 template <typename ST>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(ST) == 4 ? 4 : 3))) void step_kernel_parts(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(ST) == 4 ? RDV_PARTS_WAVES : 3))) void step_kernel_parts(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                              uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   StepArgs A = A_rest;
   A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
@@ -536,9 +542,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
 // 1 %.  With the actor kernel reading the rows in the next launch (rdv_policy_act + rdv_step per step) the pair is unchanged, 15.8 us.
 constexpr int kSplitEnvs = 256;      // envs per workgroup
 constexpr int kSplitBlock = 512;     // 8 waves
+constexpr int kSplitServiceDefault = 1;   // service waves per step wave (2: the 12-wave workgroup, see step_kernel_split)
 
-template <typename ST>
-__global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+// kSvc = 2 (round 3): TWO service waves per step wave, a 12-wave workgroup (three waves per SIMD).  Waves 4-7 prepare the chaser half
+// of every env's next initial state (rc, vc, qc, wc: Philox blocks 0-2), waves 8-11 the target half (qt, wt: blocks 2-3), which they
+// leave packed in LDS before the barrier; after it the chaser-side lane of a finished env picks the target half up from there and
+// writes the reset as before.  Round 2's stamps had the single service wave reach the barrier ~650 cycles after the step wave
+// (6,384 cycles of speculative reset against 4,316 + 1,248): each half is a shorter chain.  Same expressions, same results.
+template <typename ST, int kSvc = 1>
+__global__ __launch_bounds__(kSplitEnvs * (1 + kSvc)) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
   // at wave launch (-mllvm -amdgpu-kernarg-preload-count=16) instead of being fetched from the host-visible kernarg
@@ -548,10 +560,12 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
   using V = typename Vec4<ST>::type;
   __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // observation rows
   __shared__ unsigned long long fin_mask[kSplitEnvs / kWave];                        // per step wave: lanes to reset
+  __shared__ __attribute__((aligned(16))) V target_half[kSvc == 2 ? 2 * kSplitEnvs : 1];  // kSvc = 2: chunks c4 (qt), c6 (wt) of every env's next state
   const DevParams& P = *Pp;   // scalar loads: see step_kernel
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
   const bool step_role = wv < kSplitEnvs / kWave;
+  const bool target_role = kSvc == 2 && wv >= 2 * (kSplitEnvs / kWave);              // waves 8-11
   const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);          // both roles: the env this lane is responsible for
   const int64_t i = (int64_t)blockIdx.x * kSplitEnvs + slot_in_block;
   const int64_t wave_base = i - lane;
@@ -613,17 +627,36 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       RDV_STAMP(1);
       const double* row = nullptr;
       if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
-      reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
-      reset_aux<ST>(P, ne);
+      if (kSvc == 1) {
+        reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+        reset_aux<ST>(P, ne);
+      } else if (!target_role) {      // chaser half; the flags of the new state (:261-262) need all of it: after the barrier
+        reset_fields<ST, RESET_CHASER>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+        reset_aux<ST>(P, ne);
+      } else {                        // target half -> LDS, in storage layout
+        reset_fields<ST, RESET_TARGET>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+        V c4, c6;
+        c4.x = (ST)ne.qt[0]; c4.y = (ST)ne.qt[1]; c4.z = (ST)ne.qt[2]; c4.w = (ST)ne.qt[3];
+        c6.x = (ST)ne.wt[0]; c6.y = (ST)ne.wt[1]; c6.z = (ST)ne.wt[2]; c6.w = ST(0);
+        target_half[slot_in_block] = c4;
+        target_half[kSplitEnvs + slot_in_block] = c6;
+      }
       RDV_STAMP(2);
     }
     RDV_STAMP(3);
     __syncthreads();
     RDV_STAMP(4);
-    const unsigned long long m_reset = fin_mask[wv - kSplitEnvs / kWave];
+    const unsigned long long m_reset = target_role ? 0ull : fin_mask[wv - kSplitEnvs / kWave];
     if (m_reset != 0ull) {   // wave-uniform: some env of the step wave we serve finished its episode
       float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
       if (active && ((m_reset >> lane) & 1ull)) {
+        if (kSvc == 2) {
+          const V c4 = target_half[slot_in_block], c6 = target_half[kSplitEnvs + slot_in_block];
+          ne.qt[0] = c4.x; ne.qt[1] = c4.y; ne.qt[2] = c4.z; ne.qt[3] = c4.w;
+          ne.wt[0] = c6.x; ne.wt[1] = c6.y; ne.wt[2] = c6.z;
+          ne.flags = 0u;
+          if (reset_flags_needed(P, ne)) ne.flags = reset_flags(P, ne);
+        }
         float robs[RDV_OBS_DIM];
         observation(P, ne, robs);
         store_env<ST>(ws, A.cs, i, ne, true);
@@ -637,7 +670,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     RDV_STAMP(6);
   }
   RDV_STAMP(7);
-  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + wv)
+  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * (4 * (1 + kSvc)) + wv)
 }
 
 
@@ -804,6 +837,9 @@ static inline int64_t acos_bytes() { return align_up((int64_t)kAcosEntries * (in
 static inline int64_t prep_bytes(int64_t n, int storage) { return align_up(n * (storage == RDV_STORAGE_F64 ? slot_record_bytes<double>() : slot_record_bytes<float>()), 256); }
 static inline int64_t prep_tag_bytes(int64_t n) { return align_up(n * 4, 256); }
 static inline int64_t eval_partial_bytes(int64_t n) { return align_up(n_waves(n) * EV_SLOTS * (int64_t)sizeof(double), 256); }   // eval_summary_kernel
+static inline int64_t dev_error_bytes() { return 256; }   // the handle's device error word (RdvDeviceError bits), alone in its line
+static inline int64_t act_tmp_bytes(int64_t n) { return align_up(n * RDV_ACT_DIM * (int64_t)sizeof(float), 256); }   // clipped actions of rdv_rollout's act + step form
+static inline int64_t obs_tmp_bytes(int64_t n) { return align_up(n * RDV_OBS_DIM * (int64_t)sizeof(float), 256); }   // ... and its observation rows when [t][N][17] rows are not 16-byte aligned
 
 // Largest integer k in [-100000, 100000] for which acos(k/1e5) > theta (strict) or >= theta; -100001 if there is none.
 // acos(k/1e5) is what general.py:179 evaluates for every cosine that rounds to k*1e-5, so comparing k with this
@@ -916,12 +952,18 @@ struct RdvEnvBatch {
   int variant;       // RdvKernelVariant
   int64_t cs;        // chunk stride in envs (chunk_stride)
   int xcd_order;     // fused kernels' block order: -1 by size (xcd_order_by_size), 0 plain, 1 XCD-contiguous
+  int split_service_waves;   // split kernel: 1 or 2 service waves per step wave (RDV_SPLIT_SERVICE=1|2 in the environment at rdv_create)
   RdvRigidBody body; // rdv_set_rigid_body
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
   bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
   void* prep;        // prepared next-episode states (rdv_slots.h): records, tags
   uint32_t* prep_tag;
   double* eval_partial;   // per-wave partial sums of rdv_eval_summary
+  uint32_t* dev_error;    // device error word (RdvDeviceError bits), set by kernels with an atomic OR
+  float* act_tmp;         // [N,6] clipped actions between rdv_policy_act and rdv_step inside rdv_rollout's act + step form
+  float* obs_tmp;         // [N,17] aligned observation rows of the act + step forms when N is not a multiple of 4
+  uint32_t device_error;  // host copy: what the synchronising calls have read so far (sticky)
+  uint32_t host_error_word;
   std::vector<double> host_eval;
   bool prepared_ok;  // every slot holds what the env's next reset returns (false: prepare_kernel runs before the next slot-using launch)
 #ifdef RDV_STAMPS
@@ -934,6 +976,9 @@ static void apply_rigid_body(RdvEnvBatch* h);
 
 #define RDV_CHECK_HANDLE(h) \
   if (!(h) || (h)->magic != kMagic) return fail(RDV_ERR_BAD_HANDLE, "invalid rdv_handle")
+// calls that launch work on a handle refuse once a device fault has been read back (sticky: the state may be corrupt)
+#define RDV_CHECK_FAULT(h) \
+  if ((h)->device_error) return rdv_device_error_code((h)->device_error)
 
 // the arguments every env kernel shares (the callers add their I/O pointers)
 static void base_args(const RdvEnvBatch* h, StepArgs& A) {
@@ -967,6 +1012,14 @@ extern "C" {
 
 int rdv_version(void) { return RDV_ABI_VERSION; }
 const char* rdv_last_error(void) { return g_err; }
+
+int rdv_device_error_code(uint32_t word) {
+  if (word == 0u) return RDV_OK;
+  char what[256] = "";
+  if (word & RDV_DEVERR_LOST_SIGNAL) std::strncat(what, " LOST_SIGNAL (rdv_rollout: an env wave's bounded wait for its workgroup's slot-refill signal expired)", sizeof what - std::strlen(what) - 1);
+  if (word & ~(uint32_t)RDV_DEVERR_LOST_SIGNAL) std::strncat(what, " unknown bits", sizeof what - std::strlen(what) - 1);
+  return fail(RDV_ERR_DEVICE_FAULT, "device error word 0x%x:%s; results of this handle since the fault are not to be trusted", word, what);
+}
 
 int rdv_params_default(RdvParams* p) {
   if (!p) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_params_default: null output");
@@ -1008,7 +1061,7 @@ int rdv_params_validate(const RdvParams* p) {
 int64_t rdv_workspace_bytes(int64_t n_envs, int storage) {
   if (n_envs <= 0 || (storage != RDV_STORAGE_F32 && storage != RDV_STORAGE_F64)) return -1;
   return chunk_bytes(n_envs, storage) + stats_bytes(n_envs) + params_bytes() + acos_bytes() +
-         prep_bytes(n_envs, storage) + prep_tag_bytes(n_envs) + eval_partial_bytes(n_envs);
+         prep_bytes(n_envs, storage) + prep_tag_bytes(n_envs) + eval_partial_bytes(n_envs) + dev_error_bytes() + act_tmp_bytes(n_envs) + obs_tmp_bytes(n_envs);
 }
 
 int64_t rdv_num_envs(rdv_handle h) { return (h && h->magic == kMagic) ? h->n : -1; }
@@ -1119,7 +1172,7 @@ int rdv_policy_act(rdv_policy p, const float* obs, float* actions, int64_t n, in
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_act: obs and actions must be 16-byte aligned");
   DeviceGuard guard(p->device);
   hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((n + kPolBlockEnvs - 1) / kPolBlockEnvs)), dim3(kPolBlock), kPolLdsBytes, static_cast<hipStream_t>(stream),
-                     p->weights, obs, actions, n, deterministic, seed, counter, env_id_offset);
+                     p->weights, obs, actions, n, deterministic, seed, counter, env_id_offset, (float*)nullptr, (float*)nullptr);
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
@@ -1148,14 +1201,38 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
   if ((reinterpret_cast<uintptr_t>(out->obs) & 15) || (reinterpret_cast<uintptr_t>(out->actions) & 15) || (reinterpret_cast<uintptr_t>(out->last_obs) & 15))
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: obs, actions and last_obs must be 16-byte aligned");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_rollout: call rdv_reset first (state is undefined until reset(), as in the reference)");
+  RDV_CHECK_FAULT(h);
   DeviceGuard guard(h->device);
-  h->raw_state = false;   // the rollout kernel integrates injected (unnormalised) quaternions itself
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->general) {
+    // General rigid bodies: rdv_policy_act + rdv_step, n_steps times, on `stream` — the definition of this call's results, used as
+    // its implementation.  The per-lane RK45 inside the 168-register budget of the persistent kernel's 12-wave workgroup spilled 120
+    // dwords per lane and ran SLOWER than this loop (72 against 58 us per step at 65,536 envs, round 2): not offered any more.
+    const int64_t n = h->n;
+    const bool rows_aligned = (n & 3) == 0;      // row t of [T][N][17] starts 16-byte aligned
+    float* obs_t = rows_aligned ? out->obs : h->obs_tmp;
+    if (int rc = rdv_observe(h, obs_t, stream)) return rc;
+    for (int32_t t = 0; t < n_steps; ++t) {
+      if (!rows_aligned) RDV_HIP(hipMemcpyAsync(out->obs + (int64_t)t * n * RDV_OBS_DIM, obs_t, (size_t)n * RDV_OBS_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
+      hipLaunchKernelGGL(policy_act_kernel, dim3((unsigned)((n + kPolBlockEnvs - 1) / kPolBlockEnvs)), dim3(kPolBlock), kPolLdsBytes, s,
+                         p->weights, obs_t, h->act_tmp, n, deterministic ? 1 : 0, noise_seed, noise_counter0 + (uint64_t)t, h->env_id_offset,
+                         out->actions + (int64_t)t * n * RDV_ACT_DIM, out->log_prob ? out->log_prob + (int64_t)t * n : (float*)nullptr);
+      RDV_HIP(hipGetLastError());
+      RdvStepOut so;
+      std::memset(&so, 0, sizeof so);
+      float* obs_next = (t + 1 < n_steps) ? (rows_aligned ? out->obs + (int64_t)(t + 1) * n * RDV_OBS_DIM : h->obs_tmp) : out->last_obs;
+      so.obs = obs_next; so.reward = out->reward + (int64_t)t * n; so.done = out->done + (int64_t)t * n;
+      if (int rc = rdv_step(h, h->act_tmp, &so, stream)) return rc;
+      obs_t = obs_next;
+    }
+    return RDV_OK;
+  }
+  h->raw_state = false;   // the rollout kernel integrates injected (unnormalised) quaternions itself
   if (int rc = ensure_prepared(h, s)) return rc;
   RolloutArgs A;
   A.ws = h->ws; A.stats = h->stats; A.obs = out->obs; A.actions = out->actions; A.reward = out->reward; A.done = out->done;
   A.log_prob = out->log_prob; A.last_obs = out->last_obs; A.tape = h->tape; A.n = h->n; A.cs = h->cs; A.seed = h->seed;
-  A.prep = h->prep; A.prep_tag = h->prep_tag;
+  A.prep = h->prep; A.prep_tag = h->prep_tag; A.dev_error = h->dev_error;
   A.env_id_offset = h->env_id_offset; A.noise_seed = noise_seed; A.noise_counter0 = noise_counter0;
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps; A.deterministic = deterministic ? 1 : 0;
 #ifdef RDV_STAMPS
@@ -1163,13 +1240,8 @@ int rdv_rollout(rdv_handle h, rdv_policy p, int32_t n_steps, const RdvRolloutOut
 #endif
   const dim3 grid((unsigned)((h->n + kRollEnvs - 1) / kRollEnvs)), block(kRollBlock);
   const bool f32 = h->storage == RDV_STORAGE_F32;
-  if (h->general) {
-    if (f32) hipLaunchKernelGGL((rollout_kernel<float, true>), grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
-    else hipLaunchKernelGGL((rollout_kernel<double, true>), grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
-  } else {
-    if (f32) hipLaunchKernelGGL((rollout_kernel<float, false>), grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
-    else hipLaunchKernelGGL((rollout_kernel<double, false>), grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
-  }
+  if (f32) hipLaunchKernelGGL((rollout_kernel<float, false>), grid, block, roll_lds_bytes<float>(), s, h->dev_params, p->weights, A);
+  else hipLaunchKernelGGL((rollout_kernel<double, false>), grid, block, roll_lds_bytes<double>(), s, h->dev_params, p->weights, A);
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
@@ -1196,6 +1268,7 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->n = n_envs; h->cs = chunk_stride(n_envs, storage); h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
   { const char* x = getenv("RDV_XCD_ORDER"); h->xcd_order = (x && (x[0] == '0' || x[0] == '1') && !x[1]) ? x[0] - '0' : -1; }
+  { const char* x = getenv("RDV_SPLIT_SERVICE"); h->split_service_waves = (x && (x[0] == '1' || x[0] == '2') && !x[1]) ? x[0] - '0' : kSplitServiceDefault; }
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
   if (workspace) { h->ws = workspace; h->own_ws = false; }
   else {
@@ -1209,6 +1282,10 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->prep = reinterpret_cast<char*>(h->acos_table) + acos_bytes();
   h->prep_tag = reinterpret_cast<uint32_t*>(static_cast<char*>(h->prep) + prep_bytes(n_envs, storage));
   h->eval_partial = reinterpret_cast<double*>(reinterpret_cast<char*>(h->prep_tag) + prep_tag_bytes(n_envs));
+  h->dev_error = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(h->eval_partial) + eval_partial_bytes(n_envs));   // zeroed with the workspace
+  h->device_error = 0u; h->host_error_word = 0u;
+  h->act_tmp = reinterpret_cast<float*>(reinterpret_cast<char*>(h->dev_error) + dev_error_bytes());
+  h->obs_tmp = reinterpret_cast<float*>(reinterpret_cast<char*>(h->act_tmp) + act_tmp_bytes(n_envs));
   h->prepared_ok = false;
   h->dev.acos_table = h->acos_table;
   // every step of the set-up reports itself: which call failed, and why
@@ -1227,12 +1304,8 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   };
   raise_lds(reinterpret_cast<const void*>(rollout_kernel<float, false>), roll_lds_bytes<float>(), "hipFuncSetAttribute(rollout_kernel<float>, MaxDynamicSharedMemorySize)");
   raise_lds(reinterpret_cast<const void*>(rollout_kernel<double, false>), roll_lds_bytes<double>(), "hipFuncSetAttribute(rollout_kernel<double>, MaxDynamicSharedMemorySize)");
-  raise_lds(reinterpret_cast<const void*>(rollout_kernel<float, true>), roll_lds_bytes<float>(), "hipFuncSetAttribute(rollout_kernel<float, general>, MaxDynamicSharedMemorySize)");
-  raise_lds(reinterpret_cast<const void*>(rollout_kernel<double, true>), roll_lds_bytes<double>(), "hipFuncSetAttribute(rollout_kernel<double, general>, MaxDynamicSharedMemorySize)");
   raise_lds(reinterpret_cast<const void*>(step_many_kernel<float, false>), many_lds_bytes<float>(), "hipFuncSetAttribute(step_many_kernel<float>, MaxDynamicSharedMemorySize)");
   raise_lds(reinterpret_cast<const void*>(step_many_kernel<double, false>), many_lds_bytes<double>(), "hipFuncSetAttribute(step_many_kernel<double>, MaxDynamicSharedMemorySize)");
-  raise_lds(reinterpret_cast<const void*>(step_many_kernel<float, true>), many_lds_bytes<float>(), "hipFuncSetAttribute(step_many_kernel<float, general>, MaxDynamicSharedMemorySize)");
-  raise_lds(reinterpret_cast<const void*>(step_many_kernel<double, true>), many_lds_bytes<double>(), "hipFuncSetAttribute(step_many_kernel<double, general>, MaxDynamicSharedMemorySize)");
   if (err != hipSuccess) {
     (void)hipGetLastError();
     if (h->own_ws) (void)hipFree(h->ws);
@@ -1397,6 +1470,7 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   if (!actions || !out || !out->obs || !out->reward || !out->done)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: actions, obs, reward and done are required");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: call rdv_reset first (state is undefined until reset(), as in the reference)");
+  RDV_CHECK_FAULT(h);
   if ((reinterpret_cast<uintptr_t>(actions) & 7) || (reinterpret_cast<uintptr_t>(out->obs) & 15))   // 8-byte loads of action rows, 16-byte stores of observation rows
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: actions must be 8-byte aligned (any row of a [K,N,6] tape is) and obs 16-byte aligned");
   if (out->diag && (reinterpret_cast<uintptr_t>(out->diag) & 7)) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step: diag must be 8-byte aligned");
@@ -1420,8 +1494,14 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
 #define RDV_LAUNCH(KERNEL, GRID, BLOCK) hipLaunchKernelGGL((KERNEL), GRID, BLOCK, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A)
   const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr || A.eval != nullptr;   // either one: the evaluator build
   if (split) {
-    const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs)), block(kSplitBlock);
-    if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
+    const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs));
+    if (h->split_service_waves == 2) {
+      const dim3 block(kSplitEnvs * 3);
+      if (f32) RDV_LAUNCH((step_kernel_split<float, 2>), grid, block); else RDV_LAUNCH((step_kernel_split<double, 2>), grid, block);
+    } else {
+      const dim3 block(kSplitBlock);
+      if (f32) RDV_LAUNCH((step_kernel_split<float, 1>), grid, block); else RDV_LAUNCH((step_kernel_split<double, 1>), grid, block);
+    }
   } else {
     dim3 grid = grid_for(h->n), block(kBlock);
     A.stream_rows = h->n <= kStreamRowsMaxEnvs ? 1 : 0;
@@ -1456,11 +1536,30 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   if (out->terminal_obs || out->episode_return || out->episode_length || out->diag || out->eval)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: terminal_obs, episode_return, episode_length, diag and eval are outputs of rdv_step only");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: call rdv_reset first (state is undefined until reset(), as in the reference)");
+  RDV_CHECK_FAULT(h);
   if ((reinterpret_cast<uintptr_t>(actions) & 7) || (reinterpret_cast<uintptr_t>(out->obs) & 15))
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_step_many: actions must be 8-byte aligned and obs 16-byte aligned");
   DeviceGuard guard(h->device);
-  h->raw_state = false;   // the kernel integrates injected (unnormalised) quaternions itself
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h->general) {
+    // General rigid bodies: n_steps launches of rdv_step on `stream` (the definition of this call's results, used as its
+    // implementation): the per-lane RK45 does not fit the persistent kernel's register budget without scratch (round 2: 60 spilled
+    // dwords per lane), and a step is bound by the integrator, not by the launch boundary this call exists to remove.
+    const int64_t n = h->n;
+    const bool rows_aligned = (n & 3) == 0;
+    for (int32_t k = 0; k < n_steps; ++k) {
+      RdvStepOut so;
+      std::memset(&so, 0, sizeof so);
+      float* row = out->obs + (int64_t)k * n * RDV_OBS_DIM;
+      so.obs = rows_aligned ? row : h->obs_tmp;
+      so.reward = out->reward + (int64_t)k * n; so.done = out->done + (int64_t)k * n;
+      so.done_reason = out->done_reason ? out->done_reason + (int64_t)k * n : nullptr;
+      if (int rc = rdv_step(h, actions + (int64_t)k * n * RDV_ACT_DIM, &so, stream)) return rc;
+      if (!rows_aligned) RDV_HIP(hipMemcpyAsync(row, h->obs_tmp, (size_t)n * RDV_OBS_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return RDV_OK;
+  }
+  h->raw_state = false;   // the kernel integrates injected (unnormalised) quaternions itself
   if (int rc = ensure_prepared(h, s)) return rc;
   StepManyArgs A;
   A.ws = h->ws; A.stats = h->stats; A.actions = actions; A.obs = out->obs; A.reward = out->reward; A.done = out->done;
@@ -1469,13 +1568,8 @@ int rdv_step_many(rdv_handle h, const float* actions, int32_t n_steps, const Rdv
   A.tape_depth = h->tape_depth; A.on_done = h->on_done; A.n_steps = n_steps;
   const dim3 grid((unsigned)((h->n + kManyEnvs - 1) / kManyEnvs)), block(kManyBlock);
   const bool f32 = h->storage == RDV_STORAGE_F32;
-  if (h->general) {
-    if (f32) hipLaunchKernelGGL((step_many_kernel<float, true>), grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
-    else hipLaunchKernelGGL((step_many_kernel<double, true>), grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
-  } else {
-    if (f32) hipLaunchKernelGGL((step_many_kernel<float, false>), grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
-    else hipLaunchKernelGGL((step_many_kernel<double, false>), grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
-  }
+  if (f32) hipLaunchKernelGGL((step_many_kernel<float, false>), grid, block, many_lds_bytes<float>(), s, h->dev_params, A);
+  else hipLaunchKernelGGL((step_many_kernel<double, false>), grid, block, many_lds_bytes<double>(), s, h->dev_params, A);
   RDV_HIP(hipGetLastError());
   return RDV_OK;
 }
@@ -1589,7 +1683,10 @@ int rdv_eval_summary(rdv_handle h, const double* eval, RdvEvalSummary* out, void
   const size_t waves = (size_t)((h->n + kWave - 1) / kWave);
   h->host_eval.resize(waves * EV_SLOTS);
   RDV_HIP(hipMemcpyAsync(h->host_eval.data(), h->eval_partial, waves * EV_SLOTS * sizeof(double), hipMemcpyDeviceToHost, s));
+  RDV_HIP(hipMemcpyAsync(&h->host_error_word, h->dev_error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   RDV_HIP(hipStreamSynchronize(s));
+  h->device_error |= h->host_error_word;
+  RDV_CHECK_FAULT(h);
   double t[EV_SLOTS] = {0};
   for (size_t w = 0; w < waves; ++w)      // fixed order: reproducible sums
     for (int j = 0; j <= EV_N; ++j) t[j] += h->host_eval[w * EV_SLOTS + j];
@@ -1612,8 +1709,10 @@ int rdv_get_stats(rdv_handle h, RdvStats* out, int reset, void* stream) {
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t bytes = h->host_slots.size() * sizeof(uint64_t);
   RDV_HIP(hipMemcpyAsync(h->host_slots.data(), h->stats, bytes, hipMemcpyDeviceToHost, s));
+  RDV_HIP(hipMemcpyAsync(&h->host_error_word, h->dev_error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   if (reset) RDV_HIP(hipMemsetAsync(h->stats, 0, bytes, s));
   RDV_HIP(hipStreamSynchronize(s));
+  h->device_error |= h->host_error_word;
   std::memset(out, 0, sizeof *out);
   const size_t waves = h->host_slots.size() / kStatWords;
   for (size_t w = 0; w < waves; ++w) {   // fixed order: the sums are reproducible run to run
@@ -1623,7 +1722,7 @@ int rdv_get_stats(rdv_handle h, RdvStats* out, int reset, void* stream) {
     for (int r = 0; r < 4; ++r) out->reasons[r] += sl[ST_REASON0 + r];
     out->sum_length += (double)sl[ST_SUM_LEN]; out->sum_return += sd[ST_SUM_RET]; out->sum_delta_v += sd[ST_SUM_DV]; out->sum_delta_w += sd[ST_SUM_DW];
   }
-  return RDV_OK;
+  return rdv_device_error_code(h->device_error);   // RDV_OK unless a kernel of this handle reported a fault (the statistics are filled either way)
 }
 
 }  // extern "C"

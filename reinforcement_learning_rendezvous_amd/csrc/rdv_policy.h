@@ -217,9 +217,12 @@ __device__ __forceinline__ float actor_sample(const float* w, int lane, int dete
 
 __device__ __forceinline__ float clip_action(float v) { return (v != v) ? v : fminf(fmaxf(v, -1.0f), 1.0f); }   // np.clip (NaN stays NaN)
 
+// raw_actions [n,6] / log_prob [n] (both nullable): the sample BEFORE clipping and its log-density, the rows SB3's RolloutBuffer keeps
+// (rdv_rollout's act + step form for general rigid bodies asks for them; rdv_policy_act does not).
 __global__ __launch_bounds__(kPolBlock) void policy_act_kernel(const float* __restrict__ W, const float* __restrict__ obs,
                                                                float* __restrict__ actions, int64_t n, int deterministic,
-                                                               uint64_t seed, uint64_t counter, uint64_t env_id_offset) {
+                                                               uint64_t seed, uint64_t counter, uint64_t env_id_offset,
+                                                               float* __restrict__ raw_actions, float* __restrict__ log_prob) {
   extern __shared__ __attribute__((aligned(16))) float lds[];   // [parameters][8 x obs rows][8 x action rows]
   float* w = lds;
   const int lane = threadIdx.x & 63;
@@ -257,7 +260,13 @@ __global__ __launch_bounds__(kPolBlock) void policy_act_kernel(const float* __re
   const int r = lane & 31, h = lane >> 5;
   float a[4];
   actor_means(w, rows, lane, a);
-  (void)actor_sample(w, lane, deterministic, seed, env_id_offset + (uint64_t)(wave_base + r), counter, a);
+  const float logp = actor_sample(w, lane, deterministic, seed, env_id_offset + (uint64_t)(wave_base + r), counter, a);
+  if (log_prob && h == 0 && r < nrows) log_prob[wave_base + r] = logp;
+  if (raw_actions && r < nrows) {      // kernel-uniform pointer test; the unclipped sample, written per lane (this form is not the hot one)
+    float* dst = raw_actions + (wave_base + r) * kPolOut + 4 * h;
+    dst[0] = a[0]; dst[1] = a[1];
+    if (h == 0) { dst[2] = a[2]; dst[3] = a[3]; }
+  }
 
   // ---- actions [32,6]: own components -> LDS rows -> contiguous 8-byte-per-lane stores
   if (h == 0) {

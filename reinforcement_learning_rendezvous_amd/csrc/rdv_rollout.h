@@ -62,6 +62,7 @@ struct RolloutArgs {
   const double* tape;       // nullable [depth][N][20]
   void* prep;               // prepared next-episode states in HBM (rdv_slots.h)
   uint32_t* prep_tag;
+  uint32_t* dev_error;      // the handle's device error word (include/rdv.h, RdvDeviceError)
   int64_t n;
   int64_t cs;               // chunk stride of the workspace in envs
   uint64_t seed;            // reset RNG (as rdv_step)
@@ -300,8 +301,9 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #pragma unroll
       for (int j = 0; j < RDV_ACT_DIM; ++j) a[j] = active ? act_cur[sl * RDV_ACT_DIM + j] : 0.0f;
       StepResult r;
-      float* my_row = obs_cur + sl * RDV_OBS_DIM;     // obs_{t+1} of this env: written as it is formed (the actor reads it after the barrier)
-      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, it, active, e, a, r, RowSink{my_row});   // kRaw: a rollout may start from an injected state
+      float* my_row = obs_cur + sl * RDV_OBS_DIM;     // obs_{t+1} of this env (the actor reads it after the barrier)
+      float obs_r[RDV_OBS_DIM];                       // kept in registers to the end of the phase: see rdv_step_many.h
+      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, it, active, e, a, r, RowSink{obs_r});
 #ifdef RDV_STAMPS
       __builtin_amdgcn_sched_barrier(0); te2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -314,13 +316,23 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       stats_update(my_stats, ln < 12 ? my_stats[ln] : 0ull, ln, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
       if (resets) {
         // every slot listed in an earlier step has been refilled, and the refilling waves are done reading the job arrays: four
-        // signals per step (they were given ~2,300 cycles ago; the bound only keeps a lost signal from hanging the launch)
-        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(refills_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(kGroupWaves * (t + 1)); ++spin)
+        // signals per step (they were given ~2,300 cycles ago).  The wait is BOUNDED so that a lost signal cannot hang the launch
+        // (every wave must leave the grid): 2^22 polls of ~200 cycles each (s_sleep 2 = 128 cycles + the LDS load) = ~0.35 s at
+        // 2.4 GHz, five orders of magnitude above the expected wait.  Expiry is NOT absorbed: the wave sets RDV_DEVERR_LOST_SIGNAL in
+        // the handle's device error word before it goes on (its slots may be stale: results from here on may be wrong), and
+        // rdv_get_stats / rdv_eval_summary and every later call on the handle return RDV_ERR_DEVICE_FAULT.
+        int spin = 0;
+        while (__hip_atomic_load(refills_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(kGroupWaves * (t + 1))) {
+          if (++spin >= (1 << 22)) {
+            if (ln == 0) __hip_atomic_fetch_or(A.dev_error, (uint32_t)RDV_DEVERR_LOST_SIGNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
           __builtin_amdgcn_s_sleep(2);
+        }
         if (fin) {
           SlotRaw<ST> raw;
           slot_fetch<ST>(L, sl, raw);
-          slot_unpack<ST>(P, raw, e, my_row);     // SB3: the first obs of the next episode
+          slot_unpack<ST>(P, raw, e, obs_r);
           slot_dirty = true; wt_dirty = true;
         }
         job_kind[sl] = fin ? JOB_REFILL : JOB_NONE;   // read by the refilling waves after the next barrier
@@ -328,6 +340,8 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       } else if (fin && A.on_done == RDV_ON_DONE_HALT) {
         e.flags |= FLAG_HALTED;
       }
+#pragma unroll
+      for (int j = 0; j < RDV_OBS_DIM; ++j) my_row[j] = obs_r[j];
     }
     ROLL_T(te3);
     __syncthreads();   // observations of step t+1 are in LDS

@@ -114,8 +114,11 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
       for (int q = 0; q < 3; ++q) { a[2 * q] = pre[q].x; a[2 * q + 1] = pre[q].y; }
       if (k + 1 < K) fetch(k + 1, pre);
       StepResult r;
-      float* my_row = my_obs + lane * RDV_OBS_DIM;    // this env's staged observation row, written as it is formed
-      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, i, active, e, a, r, RowSink{my_row});   // kRaw: the tape may start from an injected state
+      float* my_row = my_obs + lane * RDV_OBS_DIM;    // this env's staged observation row
+      // the observation stays in registers until the end of the step (in the persistent loops the 17 LDS writes interleaved with the
+      // transition cost more than the registers: tools/lib_ab_persist.py, 3.54 -> 3.30 us per step here, 9.26 -> 9.09 in rdv_rollout)
+      float obs_r[RDV_OBS_DIM];
+      const bool stepped = advance<ST, false, kGeneral, !kGeneral>(SA, P, i, active, e, a, r, RowSink{obs_r});
       const bool fin = stepped && r.done;
       if (active) {
         const int64_t o = (int64_t)k * n + i;
@@ -132,13 +135,15 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
         if (take) {
           SlotRaw<ST> raw;
           slot_fetch<ST>(L, slot, raw);
-          slot_unpack<ST>(P, raw, e, my_row);     // SB3: the first obs of the next episode
+          slot_unpack<ST>(P, raw, e, obs_r);
           slot_dirty = true; wt_dirty = true;
         }
         job_kind[slot] = take ? JOB_REFILL : JOB_NONE;
         job_counter[slot] = e.episode;
         __syncthreads();   // B: the slots taken in this step are listed
       }
+#pragma unroll
+      for (int j = 0; j < RDV_OBS_DIM; ++j) my_row[j] = obs_r[j];
       wave_lds_fence();
       store_obs_rows<true>(A.obs + (int64_t)k * n * RDV_OBS_DIM, wave_base, rows, lane, my_obs, vec_rows);   // written once: non-temporal
       wave_lds_fence();   // the rows are rewritten by the next step

@@ -77,12 +77,16 @@ def evaluate_policy(policy, n_evals=50, params=None, device="cuda:0", storage="f
     return summary, per
 
 
-def env_attributes(params):
-    """``vars(env)`` of the reference env as far as it is determined by the parameters (save_new_trajectory.py:173)."""
+def env_attributes(params, bodies=None):
+    """``vars(env)`` of the reference env as far as it is determined by the parameters (save_new_trajectory.py:173).  ``bodies``: the
+    engine's ``get_rigid_body()`` — the inertia tensors the trajectory was actually integrated with (``set_rigid_body`` may have
+    replaced the constructor's 16.67 * Identity, rendezvous_env.py:75-79, :96-100); None: the constructor's values."""
     d = params.to_dict()
     out = {k: (np.array(v) if isinstance(v, list) else v) for k, v in d.items() if k in FIELD_NAMES}
-    out.update(m=MASS, inertia=np.eye(3) * INERTIA, inv_inertia=np.eye(3) / INERTIA, inertia_target=np.eye(3) * INERTIA,
-               inv_inertia_target=np.eye(3) / INERTIA, max_wt=np.radians(10), mu=3.986004418e14, Re=6371e3,
+    inertia = np.eye(3) * INERTIA if bodies is None else np.asarray(bodies["inertia"], dtype=np.float64).reshape(3, 3)
+    inertia_target = np.eye(3) * INERTIA if bodies is None else np.asarray(bodies["inertia_target"], dtype=np.float64).reshape(3, 3)
+    out.update(m=MASS, inertia=inertia, inv_inertia=np.linalg.inv(inertia), inertia_target=inertia_target,      # :80, :101
+               inv_inertia_target=np.linalg.inv(inertia_target), max_wt=np.radians(10), mu=3.986004418e14, Re=6371e3,
                reward_kwargs=dict(collision_coef=params.collision_coef, bonus_coef=params.bonus_coef,
                                   fuel_coef=params.fuel_coef, att_coef=params.att_coef))
     return out
@@ -123,7 +127,7 @@ def record_trajectories(policy, env, initial_states=None, deterministic=True, ge
     collisions = dg_h[0, :, 4] + np.where(live, dg_h[1:, :, 4], 0.0).sum(axis=0)                 # :94, :142
     successes = dg_h[0, :, 5] + np.where(live, dg_h[1:, :, 5], 0.0).sum(axis=0)                  # :95, :144-145
     d_koz = np.minimum(dg_h[0, :, 6], np.where(live, dg_h[1:, :, 6], np.inf).min(axis=0))        # :96, :143
-    attrs = env_attributes(p)
+    attrs = env_attributes(p, env.get_rigid_body() if hasattr(env, "get_rigid_body") else None)
     records = []
     for i in range(m):
         L = int(length[i])                                               # :160-170 (nan columns dropped): columns 0..L

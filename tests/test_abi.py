@@ -28,7 +28,7 @@ def _has_gpu():
 def test_library_is_built_and_loads():
     N.build()
     assert os.path.exists(N.LIB_PATH)
-    assert N.lib().rdv_version() == 2
+    assert N.lib().rdv_version() == 3
 
 
 def test_every_declared_symbol_is_exported():
@@ -42,6 +42,25 @@ def test_every_declared_symbol_is_exported():
     exported = set(re.findall(r" T (rdv_[a-z_]+)", nm))
     assert exported == set(declared)        # nothing undeclared leaks out, nothing declared is missing
     assert "orc_" not in nm                  # the oracle is not linked into the product
+
+
+def test_device_error_word_is_never_absorbed():
+    """The host check behind rdv_get_stats / rdv_eval_summary (include/rdv.h, RdvDeviceError): a kernel that gives up a bounded
+    wait (rdv_rollout.h: the env waves' poll of the slot-refill counter, 2^22 polls = ~0.35 s) sets a bit of the handle's device
+    error word; the word maps to RDV_ERR_DEVICE_FAULT with a message naming the bit.  Host-only: no GPU needed."""
+    lib = N.lib()
+    assert lib.rdv_device_error_code(0) == 0
+    rc = lib.rdv_device_error_code(N.DEVERR_LOST_SIGNAL)
+    assert rc == -7 and N.ERROR_NAMES[rc] == "RDV_ERR_DEVICE_FAULT"
+    msg = lib.rdv_last_error().decode()
+    assert "0x1" in msg and "LOST_SIGNAL" in msg and "rdv_rollout" in msg
+    assert lib.rdv_device_error_code(0x80) == -7 and "unknown bits" in lib.rdv_last_error().decode()
+    with pytest.raises(N.RdvError, match="RDV_ERR_DEVICE_FAULT"):
+        N.check(lib.rdv_device_error_code(1))
+    # the kernel's side of it is in the source: the spin sets the bit before it falls through
+    src = open(os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_rollout.h")).read()
+    spin = src[src.index("int spin = 0;"):src.index("if (fin) {", src.index("int spin = 0;"))]
+    assert "RDV_DEVERR_LOST_SIGNAL" in spin and "__hip_atomic_fetch_or(A.dev_error" in spin and "(1 << 22)" in spin
 
 
 def test_params_struct_layouts_agree():
@@ -159,16 +178,17 @@ def test_constructor_and_make_env_surface_reproduce_the_reference():
         assert N.lib().rdv_params_validate(C.byref(p)) == 0
 
 
-def test_training_kernels_use_no_scratch():
-    """The kernels of the training paths keep everything in registers: `make resource` (hipcc's kernel-resource remarks, gfx950
-    cross-compile, no GPU needed) must report ScratchSize 0 for the one-launch step kernels, the actor and the persistent kernels
-    with the reference's bodies.  (The general rigid-body instantiations of the persistent kernels, per-lane RK45 at their register
-    budget, do spill and are not in this list.)"""
+def test_no_kernel_uses_scratch_and_the_fused_step_fits_four_waves_per_simd():
+    """Every kernel the library can launch keeps everything in registers: `make resource` (hipcc's kernel-resource remarks, gfx950
+    cross-compile, no GPU needed) must report ScratchSize 0 for ALL of them — the one-launch step kernels (general rigid bodies
+    included), the actor / critic, the persistent kernels — and step_kernel_parts<float>, the kernel of batches beyond one workgroup
+    per CU, must fit 128 vector registers (four waves per SIMD).  (The general rigid-body forms of rdv_step_many / rdv_rollout, which
+    spilled in round 2, are no longer instantiated: those calls run the rdv_step loop, include/rdv.h.)"""
     csrc = os.path.join(os.path.dirname(N.__file__), "csrc")
     r = subprocess.run(["make", "-C", csrc, "resource"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     text = r.stdout + r.stderr
-    scratch = {}
+    scratch, vgprs = {}, {}
     name = None
     for line in text.splitlines():
         m = re.search(r"Function Name: (\S+)", line)
@@ -177,10 +197,17 @@ def test_training_kernels_use_no_scratch():
         m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
         if m and name:
             scratch[name] = int(m.group(1))
-    want = ["step_kernel_splitIf", "step_kernel_splitId", "step_kernel_partsIf", "step_kernel_partsId", "step_kernelIfLb0ELb0ELb0",
-            "step_kernelIdLb0ELb0ELb0", "policy_act_kernel", "policy_value_kernel", "rollout_kernelIfLb0", "rollout_kernelIdLb0",
-            "step_many_kernelIfLb0", "step_many_kernelIdLb0"]
+        m = re.search(r" VGPRs: (\d+)", line)
+        if m and name:
+            vgprs[name] = int(m.group(1))
+    want = ["step_kernel_splitIfLi1", "step_kernel_splitIdLi1", "step_kernel_splitIfLi2", "step_kernel_partsIf", "step_kernel_partsId",
+            "step_kernelIfLb0ELb0ELb0", "step_kernelIdLb0ELb0ELb0", "step_kernelIfLb0ELb1ELb0", "step_kernelIfLb1ELb1ELb0", "policy_act_kernel",
+            "policy_value_kernel", "rollout_kernelIfLb0", "rollout_kernelIdLb0", "step_many_kernelIfLb0", "step_many_kernelIdLb0"]
     for w in want:
-        hits = {k: v for k, v in scratch.items() if w in k}
-        assert hits, f"no kernel matching {w} in the resource report"
-        assert all(v == 0 for v in hits.values()), (w, hits)
+        assert any(w in k for k in scratch), f"no kernel matching {w} in the resource report"
+    assert len(scratch) >= 30
+    spilling = {k: v for k, v in scratch.items() if v != 0}
+    assert not spilling, spilling
+    assert not any("rollout_kernelIfLb1" in k or "step_many_kernelIfLb1" in k for k in scratch)      # not instantiated any more
+    parts = [v for k, v in vgprs.items() if "step_kernel_partsIf" in k]
+    assert parts and max(parts) <= 128, parts

@@ -108,10 +108,13 @@ def test_random_bodies_against_the_oracle(case):
             env.close()
 
 
-@pytest.mark.parametrize("n,storage,on_done", [(1000, "f32", "reset"), (260, "f64", "reset"), (512, "f32", "halt")])
+@pytest.mark.parametrize("n,storage,on_done", [(1000, "f32", "reset"), (260, "f64", "reset"), (512, "f32", "halt"), (1001, "f32", "reset")])
 def test_persistent_kernels_step_general_bodies_like_the_step_loop(n, storage, on_done):
-    """rdv_step_many and rdv_rollout with general rigid bodies (per-lane RK45 inside the persistent launch) against rdv_step /
-    rdv_policy_act + rdv_step, which test_random_bodies_against_the_oracle ties to the oracle: bit for bit."""
+    """rdv_step_many and rdv_rollout with general rigid bodies against rdv_step / rdv_policy_act + rdv_step, which
+    test_random_bodies_against_the_oracle ties to the oracle: bit for bit.  (Since round 3 the two calls RUN that loop for general
+    bodies — include/rdv.h — instead of a persistent kernel with the per-lane RK45 inside, which spilled; what this checks is the
+    plumbing of the rows: [K,N,...] outputs, unclipped actions, log-probabilities, the last observation, also for N not a multiple
+    of 4, where a row of [K,N,17] is not 16-byte aligned.)"""
     import os
     from helpers import GOLDEN
     from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
@@ -142,10 +145,14 @@ def test_persistent_kernels_step_general_bodies_like_the_step_loop(n, storage, o
     pr, pl = policy(), policy()
     obs = loop.obs
     ro = many.rollout(pr, 24, deterministic=False)
+    std = torch.exp(pl.log_std).to("cuda:0")
     for t in range(24):
         assert torch.equal(ro["obs"][t], obs), f"obs fed to the actor, step {t}"
         a = pl.act(obs, deterministic=False)
         assert torch.equal(torch.clamp(ro["actions"][t], -1.0, 1.0), a), f"actions, step {t}"
+        z = (ro["actions"][t] - pl.mean(obs)) / std            # SB3 DiagGaussianDistribution.log_prob of the unclipped sample
+        lp = (-0.5 * z * z - pl.log_std.to("cuda:0")).sum(dim=1) - 3.0 * float(np.log(2.0 * np.pi))
+        assert float((ro["log_prob"][t] - lp).abs().max()) < 2e-3 * max(1.0, float(z.abs().max())), f"log-probabilities, step {t}"
         obs, r, d = loop.step(a)
         assert torch.equal(ro["reward"][t], r) and torch.equal(ro["done"][t], d), f"reward / done, rollout step {t}"
     assert torch.equal(ro["last_obs"], obs)

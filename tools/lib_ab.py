@@ -11,6 +11,7 @@ import torch
 from reinforcement_learning_rendezvous_amd import _native
 if sys.argv[1] != "-":
     _native.LIB_PATH = sys.argv[1]
+    _native.STRICT = False      # an older build may lack the newest entry points
 from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
 for n in [int(x) for x in os.environ.get("AB_SIZES", "65536,32768").split(",")]:
     env = RendezvousBatch(n, device="cuda:0", storage="f32", seed=0)

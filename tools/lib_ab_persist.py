@@ -10,6 +10,7 @@ import torch
 from reinforcement_learning_rendezvous_amd import _native
 if sys.argv[1] != "-":
     _native.LIB_PATH = sys.argv[1]
+    _native.STRICT = False      # an older build may lack the newest entry points
 from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
 from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
 n, K = 65536, 64

@@ -27,6 +27,8 @@ class Carver:
     def take(self, name, nbytes):
         start = self.cur + self.skews.get(name, 0)
         self.placed[name] = start - base0
+        if start + nbytes > arena.numel():          # (a slice past the end would be silently shorter: r2's last sweep rows died in .view)
+            raise MemoryError(f"{name}: {nbytes} bytes at +{start} do not fit the {arena.numel() >> 20} MiB arena")
         self.cur = start + nbytes
         self.cur += (-self.cur) % (2 * MiB)         # next array starts on a 2 MiB boundary (+ its skew)
         return arena[start:start + nbytes]
@@ -41,13 +43,15 @@ def run(n, skews, label, steps=16, reps=3):
         t.zero_()
         return t.view(dtype).view(*shape)
     B.RendezvousBatch._alloc = alloc
-    env = B.RendezvousBatch(n, device="cuda:0", storage="f32", seed=0)
+    try:
+        env = B.RendezvousBatch(n, device="cuda:0", storage="f32", seed=0)
+        acts = [carver.take(f"actions{k}", n * 24).view(torch.float32).view(n, 6) for k in range(2)]
+    except MemoryError as exc:
+        print(f"{label:58s} n={n:8d}: skipped ({exc})", flush=True)
+        return None
     g = torch.Generator(device="cuda:0").manual_seed(1)
-    acts = []
-    for k in range(2):
-        a = carver.take(f"actions{k}", n * 24).view(torch.float32).view(n, 6)
+    for a in acts:
         a.copy_(torch.rand((n, 6), device=dev, generator=g) * 2 - 1)
-        acts.append(a)
     env.reset()
     for t in range(24):
         env.step(acts[t % 2])

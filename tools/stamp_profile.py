@@ -20,6 +20,9 @@ sys.path.insert(0, ROOT)
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+    svc = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # service waves per step wave (2: the 12-wave workgroup)
+    os.environ["RDV_SPLIT_SERVICE"] = str(svc)
+    wpg = 4 * (1 + svc)
     lib = os.path.join(ROOT, "tools", "_stamps.so")
     src = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_hip.hip")
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DRDV_STAMPS",
@@ -31,7 +34,7 @@ def main():
     env = RendezvousBatch(n, device="cuda:0", storage="f32", seed=0, variant="split")
     L = _native.lib()
     L.rdv_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
-    waves = (n + 255) // 256 * 8
+    waves = (n + 255) // 256 * wpg
     stamps = torch.zeros((waves, 10), dtype=torch.int64, device="cuda:0")
     gen = torch.Generator(device="cuda:0").manual_seed(1)
     acts = [(torch.rand((n, 6), device="cuda:0", generator=gen) * 2 - 1).contiguous() for _ in range(8)]
@@ -46,12 +49,13 @@ def main():
         torch.cuda.synchronize()
         rows.append(stamps.cpu().numpy().copy())
     s = np.stack(rows).astype(np.float64)            # [iter, wave, 10]
-    role = (np.arange(waves) % 8) >= 4
+    role = (np.arange(waves) % wpg) // 4          # 0 step, 1 service (chaser half if svc = 2), 2 service (target half)
     cyc = s[:, :, 7] - s[:, :, 0]
     real = (s[:, :, 9] - s[:, :, 8]) * 10.0          # ns
     print(f"shader clock while the kernel runs: {np.median(cyc / real):.2f} GHz (median over waves)")
     t0 = s[:, :, 8].min(axis=1, keepdims=True)
-    for name, sel in (("step waves", ~role), ("service waves", role)):
+    names = ["step waves", "service waves" if svc == 1 else "service waves (chaser half)", "service waves (target half)"]
+    for name, sel in [(names[k], role == k) for k in range(1 + svc)]:
         x = s[:, sel, :]
         d = np.diff(x[:, :, :8], axis=2)
         ent = (x[:, :, 8] - t0) * 10.0
@@ -59,6 +63,8 @@ def main():
         print(f"{name}: median cycles per phase 0>1>..>7 {np.median(d, axis=(0, 1)).astype(int).tolist()} | wave lifetime "
               f"{np.median(real[:, sel]):.0f} ns | enters {np.median(ent):.0f} ns (p95 {np.percentile(ent, 95):.0f}) and leaves "
               f"{np.median(ext):.0f} ns (p95 {np.percentile(ext, 95):.0f}, max {np.median(ext.max(axis=1)):.0f}) after the first wave")
+    at_barrier = s[:, :, 3] - s[:, :, 0]
+    print("cycles from entry to the barrier, median by role: " + ", ".join(f"{names[k]} {np.median(at_barrier[:, role == k]):.0f}" for k in range(1 + svc)))
     print(f"launch span seen by the waves (first entry -> last exit): {np.median((s[:, :, 9].max(axis=1) - s[:, :, 8].min(axis=1)) * 10):.0f} ns")
 
 
