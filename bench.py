@@ -353,7 +353,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "achieved_from_traffic": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
-                         "kernel": ("rdv::step_kernel_split" + ("<float>" if args.storage == "f32" else "<double>")) if n <= 65536 else
+                         "kernel": ("rdv::step_kernel_hint" + ("<float>" if args.storage == "f32" else "<double>")) if n <= 65536 else
                                    ("rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>")),
                          "launch_us": launch_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "achieved = 293 B x envs per launch / launch_us.  At 65,536 envs the 15 MB working set stays in the 256 MiB "
@@ -492,10 +492,12 @@ def main():
                 mid.step(acts_m[t % 4])
             us_mid = timed_steps(mid, acts_m, 64, 9)
             ach_m = ALGO_BYTES_PER_ENV_STEP * n_mid / (us_mid * 1e-6) / 1e9
+            tr_m = pmc.get(f"{args.storage}_{n_mid}")
             out["config4_global_batch_on_one_gpu"] = {"value": n_mid / (us_mid * 1e-6), "unit": "env steps/s", "envs": n_mid, "launch_us": us_mid,
                                                       "kernel": "rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>"),
                                                       "roofline": {"bound": "hbm", "achieved": ach_m, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                                                   "frac": ach_m / HBM_PEAK_GBPS, "traffic": None},
+                                                                   "frac": ach_m / HBM_PEAK_GBPS, "traffic": tr_m["bytes_per_launch"] if tr_m else None,
+                                                                   "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" if tr_m else None},
                                                       "note": "154 MB of state + I/O per launch: within the 256 MiB Infinity Cache"}
             mid.close(); del mid, acts_m
             torch.cuda.empty_cache()

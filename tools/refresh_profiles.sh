@@ -25,6 +25,7 @@ pmc() {   # key, script, args...
 }
 pmc f32_65536 "$R/tools/step_once.py" 65536 auto 8 f32 &&
 pmc f64_65536 "$R/tools/step_once.py" 65536 auto 8 f64 &&
+pmc f32_524288 "$R/tools/step_once.py" 524288 auto 8 f32 &&
 pmc f32_4194304 "$R/tools/step_once.py" 4194304 auto 8 f32 &&
 pmc persist "$R/tools/persistent_once.py"
 # one run holds both persistent kernels: tools/pmc_to_json.py picks each by name from a directory per key
