@@ -353,7 +353,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "achieved_from_traffic": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
-                         "kernel": ("rdv::step_kernel_hint" + ("<float>" if args.storage == "f32" else "<double>")) if n <= 65536 else
+                         "kernel": ("rdv::step_kernel_split" + ("<float>" if args.storage == "f32" else "<double>")) if n <= 65536 else
                                    ("rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>")),
                          "launch_us": launch_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "achieved = 293 B x envs per launch / launch_us.  At 65,536 envs the 15 MB working set stays in the 256 MiB "

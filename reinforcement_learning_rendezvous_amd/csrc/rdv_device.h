@@ -542,16 +542,15 @@ __device__ __forceinline__ void reset_uniforms(uint64_t seed, uint64_t env_id, u
 // uniforms (only wc needs R(qc) and wt needs R(qt), :256, :258), so the preparation of a next-episode state can be shared out
 // over several waves, each running a short instruction stream over the same list of envs (prepared-state slots,
 // csrc/rdv_slots.h): the expressions — hence the results, bit for bit — are those of the whole reset.
-enum ResetPart : int { RESET_ALL = -1, RESET_RC_VC = 0, RESET_QC_WC = 1, RESET_QT = 2, RESET_WT = 3,
-                       RESET_CHASER = 4 /* rc, vc, qc, wc */, RESET_TARGET = 5 /* qt, wt */ };
+enum ResetPart : int { RESET_ALL = -1, RESET_RC_VC = 0, RESET_QC_WC = 1, RESET_QT = 2, RESET_WT = 3 };
 
 // reset (:223-262): the new state (the fields of kPart; the others are left untouched) from (seed, env id, e.episode) or from a
 // tape row.  Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
 template <typename ST, int kPart>
 __device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
   constexpr bool all = kPart == RESET_ALL;
-  constexpr bool do_rv = all || kPart == RESET_RC_VC || kPart == RESET_CHASER, do_c = all || kPart == RESET_QC_WC || kPart == RESET_CHASER,
-                 do_qt = all || kPart == RESET_QT || kPart == RESET_WT || kPart == RESET_TARGET, do_wt = all || kPart == RESET_WT || kPart == RESET_TARGET;
+  constexpr bool do_rv = all || kPart == RESET_RC_VC, do_c = all || kPart == RESET_QC_WC, do_qt = all || kPart == RESET_QT || kPart == RESET_WT,
+                 do_wt = all || kPart == RESET_WT;
   if (tape_row) {
     if (do_rv) {
 #pragma unroll
@@ -675,19 +674,14 @@ struct StepResult {   // (the observation goes to the caller's sink: see observa
   int reason;    // 0 none, 1 obs, 2 time, 3 bubble, 4 attitude
 };
 
-// step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).  In two halves, so that a kernel
-// can do something between them (step_kernel_hint decides there which episodes certainly end and tells its service waves): step_env
-// is the two back to back — the same expressions in the same order whichever way it is called.
-struct StepCarry { float sum_v, sum_w; };   // what the second half needs from the action
-
-// first half (:172-180): the impulses and the Clohessy-Wiltshire propagation — rc, vc final (canonical), wc after its impulse
-template <typename ST>
-__device__ __forceinline__ void step_env_head(const DevParams& P, Env& e, const float* a, StepCarry& c) {
+// step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
+template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink>
+__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink) {
   const ST tag = ST(0);
   // :201-202, :333 need the action only through these two float32 sums: formed here, so that the six action registers die with the
   // impulses below instead of living to the end of the transition
-  c.sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
-  c.sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
+  const float sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
+  const float sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
   double Rc0[9];
   quat2mat(e.qc, Rc0);
@@ -707,24 +701,6 @@ __device__ __forceinline__ void step_env_head(const DevParams& P, Env& e, const 
   // :173, :180 delta_w = a[3:] * max_delta_w is a float64 product (max_delta_w is np.float64)
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = fma((double)a[3 + i], P.max_delta_w, e.wc[i]);
-}
-
-// The episode of `e` (after step_env_head) CERTAINLY ends in this step: the time limit (:368) or the bubble (:369) decide it, with
-// the very expressions step_env_tail evaluates later (bubble' = max(bubble - rate, min) in storage precision, |rc|^2 against bubble'^2
-// outside the rounding bracket).  A subset of the done conditions: attitude error, observation bounds and the bracketed bubble case
-// are only known at the end.
-template <typename ST>
-__device__ __forceinline__ bool certainly_done(const DevParams& P, const Env& e) {
-  const double b = canon(fmax(e.bubble - P.bubble_decrease_rate, P.bubble_min), ST(0));
-  const double b2 = b * b;
-  return (e.k + 1 >= P.k_time) || (sumsq3(e.rc) > b2 * (1.0 + 1e-15));
-}
-
-// second half (:181-221): both attitudes, flags, bookkeeping, reward, observation, done
-template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink>
-__device__ __forceinline__ void step_env_tail(const DevParams& P, Env& e, const StepCarry& c, StepResult& r, Derived& d, Sink&& sink) {
-  const ST tag = ST(0);
-  const float sum_v = c.sum_v, sum_w = c.sum_w;
   // Chaser side first (:181), then its half of the derived quantities: the attitude error's table entry (the one dependent memory
   // access of a transition) is requested here and is needed ~500 instructions later, for the reward.
   if (kGeneral) integrate_attitude_rk45(e.qc, e.wc, P.body_inertia[0], P.body_inv_inertia[0], P.body_torque[0], P.dt, P.rk_rtol, P.rk_atol);   // general inertia / torque: the reference's own integrator (both rates evolve)
@@ -785,13 +761,6 @@ __device__ __forceinline__ void step_env_tail(const DevParams& P, Env& e, const 
   const bool c_time = e.k >= P.k_time, c_att = d.k_att <= P.ka_done_max;
   r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
   r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
-}
-
-template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink>
-__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink) {
-  StepCarry c;
-  step_env_head<ST>(P, e, a, c);
-  step_env_tail<ST, kLazy, kGeneral, kRaw>(P, e, c, r, d, sink);
 }
 
 // diagnostics row (RDV_DIAG_DIM = 8) — evaluator-only

@@ -432,17 +432,6 @@ __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __rest
   refill_whole<ST>(A, *Pp, i, s2u(c5.w));
 }
 
-// The parameter block in LDS, for code that runs AFTER the kernel has stored to global memory (the by-part resets): there the
-// compiler can no longer prove that nothing has overwritten *Pp, gives up the scalar loads and fetches every field with a
-// uniform-address VECTOR load — a memory round trip per group of fields in the middle of a dozen-lane reset pass (round 3's stamps:
-// 4,400 cycles for a ~300-instruction pass).  A copy made at kernel entry (one dword per thread, in flight beside the state loads,
-// visible after the kernel's first barrier) is read with broadcast LDS loads instead.
-constexpr int kParamWords = (int)(sizeof(DevParams) / 4);
-__device__ __forceinline__ void params_to_lds(const DevParams* __restrict__ Pp, uint32_t* lds_words, int tid, int nthreads) {
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(Pp);
-  for (int k = tid; k < kParamWords; k += nthreads) lds_words[k] = src[k];
-}
-
 // ---------------------------------------------------------------------------------------------------------------
 // Fused variant with the reset shared BY PART inside the workgroup (training build: no diagnostics, reference bodies, normalised
 // state).  Everything up to the reset is step_kernel; a lane whose episode ended lists its env in LDS instead of resetting it, and
@@ -553,16 +542,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
 // 1 %.  With the actor kernel reading the rows in the next launch (rdv_policy_act + rdv_step per step) the pair is unchanged, 15.8 us.
 constexpr int kSplitEnvs = 256;      // envs per workgroup
 constexpr int kSplitBlock = 512;     // 8 waves
-constexpr int kSplitServiceDefault = 1;   // service waves per step wave (2: the 12-wave workgroup, see step_kernel_split)
-constexpr int kSplitModeDefault = 0;      // 0: step_kernel_split's speculative resets; 1: step_kernel_hint (measured slower, round 3: profiles/r03_split_hint_stamps.txt)
 
-// kSvc = 2 (round 3): TWO service waves per step wave, a 12-wave workgroup (three waves per SIMD).  Waves 4-7 prepare the chaser half
-// of every env's next initial state (rc, vc, qc, wc: Philox blocks 0-2), waves 8-11 the target half (qt, wt: blocks 2-3), which they
-// leave packed in LDS before the barrier; after it the chaser-side lane of a finished env picks the target half up from there and
-// writes the reset as before.  Round 2's stamps had the single service wave reach the barrier ~650 cycles after the step wave
-// (6,384 cycles of speculative reset against 4,316 + 1,248): each half is a shorter chain.  Same expressions, same results.
-template <typename ST, int kSvc = 1>
-__global__ __launch_bounds__(kSplitEnvs * (1 + kSvc)) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
+// Round 3 measured the two obvious ways of shortening what stands in front of the barrier (both bit-identical, both SLOWER; code in
+// commits 794a540 and 8ad2438, evidence under profiles/):
+//  - the speculative reset split over TWO service waves per step wave (12-wave workgroup, chaser half | target half in LDS): the
+//    halves' chains are shorter (5,356 and 6,436 cycles to the barrier against 6,596) and the launch takes 7.01 us against 6.78
+//    (profiles/r03_split_service_waves_stamps.txt).  What bounds the time to the barrier is not either wave's chain but the SIMD's
+//    vector issue: SQ_ACTIVE_INST_VALU has the step wave's ~940 and the service wave's ~900 instructions keep the VALU busy for nearly
+//    all of those cycles (profiles/r03_sq_counters_closed_loop.csv);
+//  - so the work itself would have to go: the step waves post, a quarter into the transition, which episodes CERTAINLY end (time limit,
+//    bubble) and the service waves reset only those, by part, beside the rest of the transition (step_kernel_hint): 7.99 us.  14 % of
+//    this workload's ends are attitude-error ends, known only after the chaser's attitude step — 83 % of the workgroups have one per
+//    step and pay a third barrier — and a dozen-lane by-part pass takes 4,400 cycles, not 1,200: after the kernel's first global
+//    store the compiler fetches every parameter field with a uniform-address VECTOR load (profiles/r03_split_hint_stamps.txt).
+template <typename ST>
+__global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
   // at wave launch (-mllvm -amdgpu-kernarg-preload-count=16) instead of being fetched from the host-visible kernarg
@@ -572,12 +566,10 @@ __global__ __launch_bounds__(kSplitEnvs * (1 + kSvc)) void step_kernel_split(voi
   using V = typename Vec4<ST>::type;
   __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // observation rows
   __shared__ unsigned long long fin_mask[kSplitEnvs / kWave];                        // per step wave: lanes to reset
-  __shared__ __attribute__((aligned(16))) V target_half[kSvc == 2 ? 2 * kSplitEnvs : 1];  // kSvc = 2: chunks c4 (qt), c6 (wt) of every env's next state
   const DevParams& P = *Pp;   // scalar loads: see step_kernel
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = threadIdx.x >> 6;
   const bool step_role = wv < kSplitEnvs / kWave;
-  const bool target_role = kSvc == 2 && wv >= 2 * (kSplitEnvs / kWave);              // waves 8-11
   const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);          // both roles: the env this lane is responsible for
   const int64_t i = (int64_t)blockIdx.x * kSplitEnvs + slot_in_block;
   const int64_t wave_base = i - lane;
@@ -639,188 +631,22 @@ __global__ __launch_bounds__(kSplitEnvs * (1 + kSvc)) void step_kernel_split(voi
       RDV_STAMP(1);
       const double* row = nullptr;
       if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
-      if (kSvc == 1) {
-        reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
-        reset_aux<ST>(P, ne);
-      } else if (!target_role) {      // chaser half; the flags of the new state (:261-262) need all of it: after the barrier
-        reset_fields<ST, RESET_CHASER>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
-        reset_aux<ST>(P, ne);
-      } else {                        // target half -> LDS, in storage layout
-        reset_fields<ST, RESET_TARGET>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
-        V c4, c6;
-        c4.x = (ST)ne.qt[0]; c4.y = (ST)ne.qt[1]; c4.z = (ST)ne.qt[2]; c4.w = (ST)ne.qt[3];
-        c6.x = (ST)ne.wt[0]; c6.y = (ST)ne.wt[1]; c6.z = (ST)ne.wt[2]; c6.w = ST(0);
-        target_half[slot_in_block] = c4;
-        target_half[kSplitEnvs + slot_in_block] = c6;
-      }
+      reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+      reset_aux<ST>(P, ne);
       RDV_STAMP(2);
     }
     RDV_STAMP(3);
     __syncthreads();
     RDV_STAMP(4);
-    const unsigned long long m_reset = target_role ? 0ull : fin_mask[wv - kSplitEnvs / kWave];
+    const unsigned long long m_reset = fin_mask[wv - kSplitEnvs / kWave];
     if (m_reset != 0ull) {   // wave-uniform: some env of the step wave we serve finished its episode
       float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
       if (active && ((m_reset >> lane) & 1ull)) {
-        if (kSvc == 2) {
-          const V c4 = target_half[slot_in_block], c6 = target_half[kSplitEnvs + slot_in_block];
-          ne.qt[0] = c4.x; ne.qt[1] = c4.y; ne.qt[2] = c4.z; ne.qt[3] = c4.w;
-          ne.wt[0] = c6.x; ne.wt[1] = c6.y; ne.wt[2] = c6.z;
-          ne.flags = 0u;
-          if (reset_flags_needed(P, ne)) ne.flags = reset_flags(P, ne);
-        }
         float robs[RDV_OBS_DIM];
         observation(P, ne, robs);
         store_env<ST>(ws, A.cs, i, ne, true);
 #pragma unroll
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
-      }
-      wave_lds_fence();
-      RDV_STAMP(5);
-      store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
-    }
-    RDV_STAMP(6);
-  }
-  RDV_STAMP(7);
-  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * (4 * (1 + kSvc)) + wv)
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------
-// Split-role variant WITH AN EARLY HINT (round 3) — what RDV_VARIANT_SPLIT launches for auto-resetting batches.
-// Round 3's stamps and counters (profiles/r03_split_service_waves_stamps.txt, r03_sq_counters_closed_loop.csv) showed what bounds
-// step_kernel_split before its barrier: not the length of either wave's chain — giving the speculative reset to two service waves
-// shortened both chains and the launch got slower — but the SIMD's vector issue: a step wave (~940 instructions) and a service wave
-// (~900: a whole reset for every env, used by ~5 % of them) together keep the VALU busy for nearly all of the ~6,600 cycles in front
-// of the barrier.  So the work itself has to go.  Most episode ends are decided EARLY in a transition: the time limit is known at
-// load, and leaving the bubble (99 % of the ends under random actions) as soon as the Clohessy-Wiltshire propagation has produced the
-// new position, a quarter of the way into the chain.  The step waves run the first half of the transition (step_env_head), mark the
-// envs whose episode certainly ends (certainly_done: the expressions the done test itself evaluates) and meet the service waves at
-// a first barrier; the service waves then compute the reset of THOSE envs only — shared by part (rc+vc+bookkeeping | qc+wc | qt | wt:
-// slot_refill_part, ~150-350 instructions per wave over one compacted list of ~13 envs) straight into the envs' state chunks in HBM
-// (the step waves loaded the old state long before) and into a second set of observation rows in LDS — while the step waves finish
-// the transition.  After the second barrier the service wave of a step wave swaps the prepared rows in and stores the block, as
-// before.  An end that was NOT certain early (attitude error, observation out of its Box, the bubble inside its rounding bracket)
-// is rare; it is reset after the second barrier, by part, behind a third barrier that is executed only by workgroups that have one.
-// Same expressions on the same inputs as every other variant: bit-identical results (tests/test_gpu_slots.py).
-template <typename ST>
-__global__ __launch_bounds__(kSplitBlock) void step_kernel_hint(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
-                                                                 uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
-  StepArgs A = A_rest;
-  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
-  using V = typename Vec4<ST>::type;
-  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];       // observation rows of the step
-  __shared__ __attribute__((aligned(16))) float next_rows[kSplitEnvs * RDV_OBS_DIM];   // first observation of the next episode, hinted envs
-  __shared__ unsigned long long fin_mask[kSplitEnvs / kWave];                            // per step wave: lanes to reset
-  __shared__ uint32_t job_kind[kSplitEnvs];       // JOB_REFILL: the episode certainly ends (written before the first barrier)
-  __shared__ uint32_t job_late[kSplitEnvs];       // JOB_REFILL: it ended without having been hinted (written before the second)
-  __shared__ uint32_t job_counter[kSplitEnvs];    // episode index of every env
-  __shared__ uint16_t lists[kGroupWaves * kSplitEnvs];
-  __shared__ uint32_t late_any;
-  __shared__ __attribute__((aligned(16))) uint32_t params_lds[kParamWords];   // the parameter block for the reset passes (params_to_lds)
-  static_assert(kSplitEnvs == kGroupEnvs, "refill_pass_lds is written for 256-env workgroups");
-  const DevParams& P = *Pp;   // scalar loads: see step_kernel
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wv = threadIdx.x >> 6;
-  const bool step_role = wv < kSplitEnvs / kWave;
-  const int slot_in_block = threadIdx.x & (kSplitEnvs - 1);          // both roles: the env this lane is responsible for
-  const int64_t block_base = (int64_t)blockIdx.x * kSplitEnvs;
-  const int64_t i = block_base + slot_in_block;
-  const int64_t wave_base = i - lane;
-  const int64_t n = A.n;
-  const bool active = i < n;
-  const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
-  V* ws = reinterpret_cast<V*>(A.ws);
-  RDV_STAMP_DECL
-  RDV_STAMP(0);
-
-  if (step_role) {
-    // ------------------------------------------------------------------ step waves
-    float* wl = stage + wv * (kWave * RDV_OBS_DIM);
-    Env e;
-    StepResult r;
-    r.done = 0; r.reason = 0; r.reward = 0.0f; r.reward64 = 0.0;
-    if (active) load_env<ST>(ws, A.cs, i, e);
-    uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-    const uint64_t slot_pre = stats_preload(slot, lane);
-    float a[RDV_ACT_DIM];
-    load_actions(A.actions, wave_base, lane, active, a);
-    RDV_STAMP(1);
-    const bool stepping = active && !(e.flags & FLAG_HALTED);
-    StepCarry carry;
-    carry.sum_v = 0.0f; carry.sum_w = 0.0f;
-    if (stepping) step_env_head<ST>(P, e, a, carry);
-    const bool certain = stepping && certainly_done<ST>(P, e);
-    job_kind[slot_in_block] = certain ? JOB_REFILL : JOB_NONE;
-    job_counter[slot_in_block] = active ? e.episode : 0u;
-    if (threadIdx.x == 0) late_any = 0u;
-    __syncthreads();   // 1: the hints are posted
-    RDV_STAMP(2);
-    // observation rows: own row -> LDS as it is formed, and kept in registers (after the second barrier the LDS row may already hold
-    // the next episode's observation when the terminal one is stored)
-    float obs_r[RDV_OBS_DIM];
-    float* my_row = wl + lane * RDV_OBS_DIM;
-    auto both = [&](int j, float v) { obs_r[j] = v; my_row[j] = v; };
-    bool stepped = false;
-    if (!active) {
-#pragma unroll
-      for (int j = 0; j < RDV_OBS_DIM; ++j) both(j, 0.0f);
-    } else if (!stepping) {
-      observation_to(P, e, both);
-      r.done = 1;
-    } else {
-      Derived d;
-      step_env_tail<ST, true>(P, e, carry, r, d, both);
-      stepped = true;
-    }
-    const bool fin = stepped && r.done;     // on_done == RESET here: every finished env resets
-    const unsigned long long m_reset = __ballot(fin);
-    const bool late = fin && !certain;
-    if (lane == 0) fin_mask[wv] = m_reset;
-    job_late[slot_in_block] = late ? JOB_REFILL : JOB_NONE;
-    if (__ballot(late) != 0ull && lane == 0) late_any = 1u;
-    RDV_STAMP(3);
-    __syncthreads();   // 2: the resets of the hinted envs are in HBM / next_rows; which envs ended is known
-    RDV_STAMP(4);
-    const bool late_wg = late_any != 0u;    // workgroup-uniform
-    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-    store_step_outputs<true>(A, i, active, fin, r, e, obs_r);
-    if (m_reset == 0ull) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
-    RDV_STAMP(5);
-    if (stepped && !fin) store_env<ST>(ws, A.cs, i, e, false);   // 6 x 16-byte-per-lane stores; a finished env's new state: service waves
-    RDV_STAMP(6);
-    if (late_wg) __syncthreads();   // 3 (rare)
-  } else {
-    // ------------------------------------------------------------------ service waves: part `role` of every reset of the workgroup
-    const int role = wv - kSplitEnvs / kWave;
-    uint16_t* list = lists + role * kSplitEnvs;
-    params_to_lds(Pp, params_lds, (int)threadIdx.x - kSplitEnvs, kSplitEnvs);
-    const DevParams& Pl = *reinterpret_cast<const DevParams*>(params_lds);
-    RDV_STAMP(1);
-    __syncthreads();   // 1
-    RDV_STAMP(2);
-    {
-      LiveStore<ST> E;     // the next state straight into the env's chunks, its first observation into next_rows
-      E.ws = ws; E.rows = next_rows; E.cs = A.cs; E.base = block_base;
-      refill_pass_lds<ST>(role, lane, Pl, E, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
-    }
-    RDV_STAMP(3);
-    __syncthreads();   // 2
-    RDV_STAMP(4);
-    const bool late_wg = late_any != 0u;
-    if (late_wg) {       // rare: ends that were not certain early — the same parts, now into the rows of the step themselves
-      LiveStore<ST> L;
-      L.ws = ws; L.rows = stage; L.cs = A.cs; L.base = block_base;
-      refill_pass_lds<ST>(role, lane, Pl, L, job_late, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
-      __syncthreads();   // 3
-    }
-    const unsigned long long m_reset = fin_mask[role];
-    if (m_reset != 0ull) {   // wave-uniform: some env of the step wave we serve finished its episode
-      float* wl = stage + role * (kWave * RDV_OBS_DIM);
-      if (job_kind[slot_in_block] == JOB_REFILL) {      // hinted (hence finished): its prepared first observation replaces the terminal one
-        const float* src = next_rows + slot_in_block * RDV_OBS_DIM;
-#pragma unroll
-        for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = src[j];
       }
       wave_lds_fence();
       RDV_STAMP(5);
@@ -1111,8 +937,6 @@ struct RdvEnvBatch {
   int variant;       // RdvKernelVariant
   int64_t cs;        // chunk stride in envs (chunk_stride)
   int xcd_order;     // fused kernels' block order: -1 by size (xcd_order_by_size), 0 plain, 1 XCD-contiguous
-  int split_service_waves;   // split kernel: 1 or 2 service waves per step wave (RDV_SPLIT_SERVICE=1|2 in the environment at rdv_create)
-  int split_mode;            // 0: speculative resets (step_kernel_split), 1: early hint + by-part resets (step_kernel_hint); RDV_SPLIT_MODE=0|1
   RdvRigidBody body; // rdv_set_rigid_body
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
   bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
@@ -1428,8 +1252,6 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->n = n_envs; h->cs = chunk_stride(n_envs, storage); h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
   { const char* x = getenv("RDV_XCD_ORDER"); h->xcd_order = (x && (x[0] == '0' || x[0] == '1') && !x[1]) ? x[0] - '0' : -1; }
-  { const char* x = getenv("RDV_SPLIT_MODE"); h->split_mode = (x && (x[0] == '0' || x[0] == '1') && !x[1]) ? x[0] - '0' : kSplitModeDefault; }
-  { const char* x = getenv("RDV_SPLIT_SERVICE"); h->split_service_waves = (x && (x[0] == '1' || x[0] == '2') && !x[1]) ? x[0] - '0' : kSplitServiceDefault; }
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
   if (workspace) { h->ws = workspace; h->own_ws = false; }
   else {
@@ -1656,16 +1478,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr || A.eval != nullptr;   // either one: the evaluator build
   if (split) {
     const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs));
-    if (h->split_mode == 1 && h->on_done == RDV_ON_DONE_RESET) {      // early hint + by-part resets (step_kernel_hint)
-      const dim3 block(kSplitBlock);
-      if (f32) RDV_LAUNCH(step_kernel_hint<float>, grid, block); else RDV_LAUNCH(step_kernel_hint<double>, grid, block);
-    } else if (h->split_service_waves == 2) {
-      const dim3 block(kSplitEnvs * 3);
-      if (f32) RDV_LAUNCH((step_kernel_split<float, 2>), grid, block); else RDV_LAUNCH((step_kernel_split<double, 2>), grid, block);
-    } else {
-      const dim3 block(kSplitBlock);
-      if (f32) RDV_LAUNCH((step_kernel_split<float, 1>), grid, block); else RDV_LAUNCH((step_kernel_split<double, 1>), grid, block);
-    }
+    const dim3 block(kSplitBlock);
+    if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
   } else {
     dim3 grid = grid_for(h->n), block(kBlock);
     A.stream_rows = h->n <= kStreamRowsMaxEnvs ? 1 : 0;

@@ -200,7 +200,7 @@ def test_no_kernel_uses_scratch_and_the_fused_step_fits_four_waves_per_simd():
         m = re.search(r" VGPRs: (\d+)", line)
         if m and name:
             vgprs[name] = int(m.group(1))
-    want = ["step_kernel_splitIfLi1", "step_kernel_splitIdLi1", "step_kernel_splitIfLi2", "step_kernel_partsIf", "step_kernel_partsId",
+    want = ["step_kernel_splitIf", "step_kernel_splitId", "step_kernel_partsIf", "step_kernel_partsId",
             "step_kernelIfLb0ELb0ELb0", "step_kernelIdLb0ELb0ELb0", "step_kernelIfLb0ELb1ELb0", "step_kernelIfLb1ELb1ELb0", "policy_act_kernel",
             "policy_value_kernel", "rollout_kernelIfLb0", "rollout_kernelIdLb0", "step_many_kernelIfLb0", "step_many_kernelIdLb0"]
     for w in want:

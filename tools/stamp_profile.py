@@ -20,8 +20,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
-    svc = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # service waves per step wave (2: the 12-wave workgroup)
-    os.environ["RDV_SPLIT_SERVICE"] = str(svc)
+    svc = 1          # service waves per step wave (round 3 also stamped a 12-wave workgroup with two: profiles/r03_split_service_waves_stamps.txt)
     wpg = 4 * (1 + svc)
     lib = os.path.join(ROOT, "tools", "_stamps.so")
     src = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_hip.hip")
