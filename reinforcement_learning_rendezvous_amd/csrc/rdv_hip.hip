@@ -1068,23 +1068,53 @@ static int create_mlp(const float* w1, const float* b1, const float* w2, const f
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(RDV_ERR_NO_DEVICE, "no HIP device available: this library has no CPU path");
   if (device < 0 || device >= count) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_policy_create: device %d out of range [0,%d)", device, count);
   DeviceGuard guard(device);
-  // The parameter block of csrc/rdv_policy.h: weight fragments in MFMA A-operand order, each weight split into three bf16 terms
-  // (w = hi + mid + lo to 24 bits), then the biases in accumulator order, exp(log_std) and log_std.  SB3 stores nn.Linear weights
-  // as [out, in], which is the A operand of the transposed product Y = W . X as it stands.
+  // The parameter block of csrc/rdv_policy.h: weight fragments in MFMA A-operand order, each weight scaled by its layer's power of
+  // two and split into two fp16 terms (w * 2^s = hi + lo to 22 bits), then the biases in accumulator order (times the accumulator's
+  // scale), exp(log_std), log_std and the inverse scales.  SB3 stores nn.Linear weights as [out, in], which is the A operand of the
+  // transposed product Y = W . X as it stands.
   std::vector<float> packed((size_t)kPolFloats, 0.0f);
   uint16_t* frags = reinterpret_cast<uint16_t*>(packed.data());
-  auto bf16_rn = [](float x) -> uint16_t {   // round to nearest even
+  auto f16_rn = [](float x) -> uint16_t {   // IEEE binary16, round to nearest even (|x| < 65504 here; subnormals kept)
     uint32_t u; std::memcpy(&u, &x, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const uint32_t a = u & 0x7fffffffu;
+    if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                  // NaN
+    if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                 // >= 65520: inf
+    if (a < 0x33000001u) return (uint16_t)sign;                              // < 2^-25: 0
+    int e = (int)(a >> 23) - 127;
+    uint32_t m = (a & 0x7fffffu) | 0x800000u;                                // 24-bit significand
+    int shift = e >= -14 ? 13 : 13 + (-14 - e);                              // normal: keep 11 bits; subnormal: fewer
+    uint32_t q = m >> shift;
+    const uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) ++q;
+    uint32_t out = e >= -14 ? (uint32_t)((e + 15) << 10) + (q - 0x400u) : q;   // (a carry out of the significand bumps the exponent)
+    return (uint16_t)(sign | out);
   };
-  auto bf16_f = [](uint16_t b) -> float { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; };
-  auto put = [&](int frag0, int mt_count, int ks_count, int mt, int ks, int lane, int j, float wv) {
-    const uint16_t hi = bf16_rn(wv); const float r1 = wv - bf16_f(hi);
-    const uint16_t mid = bf16_rn(r1); const float r2 = r1 - bf16_f(mid);
-    const uint16_t term[3] = {hi, mid, bf16_rn(r2)};
-    for (int q = 0; q < 3; ++q) frags[((size_t)(frag0 + (q * mt_count + mt) * ks_count + ks) * 64 + (size_t)lane) * 8 + (size_t)j] = term[q];
+  auto f16_f = [](uint16_t hbits) -> float {
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16, e = (hbits >> 10) & 0x1fu, m = hbits & 0x3ffu;
+    float mag;
+    if (e == 0) mag = std::ldexp((float)m, -24);
+    else if (e == 31) mag = m ? NAN : INFINITY;
+    else mag = std::ldexp((float)(m | 0x400u), (int)e - 25);
+    return sign ? -mag : mag;
+  };
+  // per-layer weight scale: the largest power of two (at most 2^10) that keeps every |w| * 2^s below 2^15
+  auto layer_shift = [](const float* wts, int count) {
+    float mx = 0.0f;
+    for (int i = 0; i < count; ++i) mx = std::fmax(mx, std::fabs(wts[i]));
+    int sft = 10;
+    while (sft > -20 && std::ldexp(mx, sft) >= 32768.0f) --sft;
+    return sft;
+  };
+  for (int i = 0; i < kPolHid * kPolIn; ++i) if (!std::isfinite(w1[i])) return fail(RDV_ERR_BAD_PARAMS, "rdv_policy_create: non-finite weight");
+  for (int i = 0; i < kPolHid * kPolHid; ++i) if (!std::isfinite(w2[i])) return fail(RDV_ERR_BAD_PARAMS, "rdv_policy_create: non-finite weight");
+  for (int i = 0; i < out_dim * kPolHid; ++i) if (!std::isfinite(w3[i])) return fail(RDV_ERR_BAD_PARAMS, "rdv_policy_create: non-finite weight");
+  const int sh1 = layer_shift(w1, kPolHid * kPolIn), sh2 = layer_shift(w2, kPolHid * kPolHid), sh3 = layer_shift(w3, out_dim * kPolHid);
+  auto put = [&](int frag0, int mt_count, int ks_count, int mt, int ks, int lane, int j, float wv, int sft) {
+    const float ws = std::ldexp(wv, sft);
+    const uint16_t hi = f16_rn(ws);
+    const uint16_t term[2] = {hi, f16_rn(ws - f16_f(hi))};
+    for (int q = 0; q < 2; ++q) frags[((size_t)(frag0 + (q * mt_count + mt) * ks_count + ks) * 64 + (size_t)lane) * 8 + (size_t)j] = term[q];
   };
   for (int lane = 0; lane < 64; ++lane) {
     const int r = lane & 31, h = lane >> 5;
@@ -1092,27 +1122,29 @@ static int create_mlp(const float* w1, const float* b1, const float* w2, const f
       for (int mt = 0; mt < 2; ++mt) {
         for (int s = 0; s < 2; ++s) {                                   // layer 1: natural k order (its B operand is built from obs rows)
           const int k = 16 * s + 8 * h + j;
-          put(kPolW1Frag, 2, 2, mt, s, lane, j, k < kPolIn ? w1[(32 * mt + r) * kPolIn + k] : 0.0f);
+          put(kPolW1Frag, 2, 2, mt, s, lane, j, k < kPolIn ? w1[(32 * mt + r) * kPolIn + k] : 0.0f, sh1);
         }
         for (int ks = 0; ks < 4; ++ks) {                                // layer 2: k order of an accumulator tile used as B operand
           const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
-          put(kPolW2Frag, 2, 4, mt, ks, lane, j, w2[(32 * mt + r) * kPolHid + k]);
+          put(kPolW2Frag, 2, 4, mt, ks, lane, j, w2[(32 * mt + r) * kPolHid + k], sh2);
         }
       }
       for (int ks = 0; ks < 4; ++ks) {                                  // head: 6 output rows of a 32-row tile
         const int k = 32 * (ks >> 1) + 16 * (ks & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
-        put(kPolW3Frag, 1, 4, 0, ks, lane, j, r < out_dim ? w3[r * kPolHid + k] : 0.0f);
+        put(kPolW3Frag, 1, 4, 0, ks, lane, j, r < out_dim ? w3[r * kPolHid + k] : 0.0f, sh3);
       }
     }
   }
+  const float acc1 = std::ldexp(1.0f, kPolXShift + sh1), acc2 = std::ldexp(1.0f, kPolXShift + sh2), acc3 = std::ldexp(1.0f, kPolXShift + sh3);
   for (int mt = 0; mt < 2; ++mt)
     for (int h = 0; h < 2; ++h)
       for (int e = 0; e < 16; ++e) {
         const int row = (e & 3) + 8 * (e >> 2) + 4 * h;                 // accumulator register e of lane half h -> row of the tile
-        packed[kPolB1 + (mt * 2 + h) * 16 + e] = b1[32 * mt + row];
-        packed[kPolB2 + (mt * 2 + h) * 16 + e] = b2[32 * mt + row];
-        if (mt == 0) packed[kPolB3 + h * 16 + e] = row < out_dim ? b3[row] : 0.0f;
+        packed[kPolB1 + (mt * 2 + h) * 16 + e] = b1[32 * mt + row] * acc1;
+        packed[kPolB2 + (mt * 2 + h) * 16 + e] = b2[32 * mt + row] * acc2;
+        if (mt == 0) packed[kPolB3 + h * 16 + e] = row < out_dim ? b3[row] * acc3 : 0.0f;
       }
+  packed[kPolScale + 0] = 1.0f / acc1; packed[kPolScale + 1] = 1.0f / acc2; packed[kPolScale + 2] = 1.0f / acc3;
   if (log_std) for (int j = 0; j < out_dim; ++j) { packed[kPolStd + j] = std::exp(log_std[j]); packed[kPolLogStd + j] = log_std[j]; }
   RdvPolicyNet* p = new (std::nothrow) RdvPolicyNet();
   if (!p) return fail(RDV_ERR_OUT_OF_MEMORY, "rdv_policy_create: host allocation failed");

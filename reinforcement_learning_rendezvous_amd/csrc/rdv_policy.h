@@ -6,20 +6,27 @@
 // 60-70 us per step even when replayed from a HIP graph.  This IS a dense contraction, so it runs on the matrix cores, with
 // fp32-level accuracy (a bf16 or fp16 product alone would move the actions in the third decimal, i.e. change the trajectories):
 //
-//   - every fp32 operand x is split into three bf16 terms, x = hi + mid + lo exactly to 24 bits (hi = bf16(x), mid = bf16(x - hi),
-//     lo = bf16(x - hi - mid)); a product a.w is the sum of the six leading term products (hi.hi, hi.mid, mid.hi, hi.lo, mid.mid,
-//     lo.hi — the dropped ones are below 2^-24 of it), each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16.  That is six
-//     bf16 MFMAs of 32 cycles per 16 k instead of eight fp32-input MFMAs of 64 cycles (0.37x the matrix time), and — measured on the
-//     first version of this kernel, which used v_mfma_f32_32x32x2_f32 — the fp32-input MFMA runs at the fp32 VECTOR rate and its
-//     time adds to the vector work of the SIMD's waves (6.9 us without the MFMAs, 12.2 us with them, whatever the wave arrangement,
-//     priorities or operand prefetch), while the bf16 MFMA is a pipe of its own that runs beside the tanh / split / noise work;
+//   - every fp32 operand x is scaled by a power of two (2^10 for activations and inputs, a per-layer power for the weights: exact) and
+//     split into TWO fp16 terms, x = hi + lo to 22 bits (hi = fp16(x), lo = fp16(x - hi)); a product a.w is the sum of the three
+//     leading term products (hi.hi, hi.lo, lo.hi — the dropped lo.lo is below 2^-22 of it), each exact in the fp32 accumulator of
+//     v_mfma_f32_32x32x16_f16; the accumulator is scaled back by the exact inverse power.  Measured against an fp64 evaluation of the
+//     shipped network on 104k observations (NumPy emulation of the scheme): max error 1.4e-6 — below that of a plain fp32 GEMM
+//     evaluation of the same network (4.4e-6), i.e. fp32-level accuracy.  Three fp16 MFMAs of 32 cycles per 16 k instead of eight
+//     fp32-input MFMAs of 64 cycles, and — measured on the first version of this kernel, which used v_mfma_f32_32x32x2_f32 — the
+//     fp32-input MFMA runs at the fp32 VECTOR rate and its time adds to the vector work of the SIMD's waves, while the 16-bit MFMA is a
+//     pipe of its own that runs beside the tanh / split / noise work.  (Rounds 1-2 used THREE bf16 terms and six products, 7.4e-7: the
+//     round-3 counters — profiles/r03_sq_counters_closed_loop.csv — showed the actor VALU-bound, with the three-term splits its largest
+//     item; fp16's 11-bit significand needs one term less for the same 22+ bits.  The scaling keeps the lo terms out of fp16's
+//     subnormal range for |x| >= 1.2e-4; below that the loss is <= 6e-8 absolute.  Inputs are clamped to +-63 before the split —
+//     no effect inside the observation Box [-1, 1] — so that nothing overflows fp16's range.);
 //   - the layers are computed TRANSPOSED, Y[features][envs] = W . X: a wave owns 32 envs (the N of a 32x32 tile), the weights are the
 //     A operand, and a layer's accumulator tile — column (env) on the lane, rows (features) in the 16 registers — is directly the
 //     B operand of the next layer (cdna_hip_programming.md, "an accumulator tile as the next MFMA's operand"): activations never
 //     leave the registers, there is no LDS image, no transposition and no wave synchronisation between the layers.  The k order of
 //     such a fragment is permuted (element j of lane half h is feature 16s + 8(j>>2) + 4h + (j&3)); the host stores the weight
-//     fragments in that order, already split into bf16 terms, one 16-byte read per lane and fragment;
-//   - bias = accumulator initial value, tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32; the 64 -> 6 head is one more
+//     fragments in that order, already scaled and split into fp16 terms, one 16-byte read per lane and fragment;
+//   - bias (scaled) = accumulator initial value, tanh = 1 - 2/(2^(2x log2 e) + 1) on v_exp_f32 / v_rcp_f32, with the accumulator's
+//     scale folded into the exponent's constant and the next layer's 2^10 into the result; the 64 -> 6 head is one more
 //     (padded) tile, so a lane ends up with 4 (lower half) or 2 (upper half) of its env's action means;
 //   - observations in / actions out are staged through LDS so that global accesses are contiguous.
 #pragma once
@@ -39,39 +46,42 @@ constexpr int kPolBlockEnvs = (kPolBlock / 64) * kPolWaveEnvs;   // 256
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float pol_f4 __attribute__((ext_vector_type(4)));
 typedef float pol_f2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-// Packed parameter block (built by rdv_policy_create, copied to LDS by every workgroup).  bf16 section: weight FRAGMENTS of
-// 64 lanes x 8 bf16 (1 KiB; lane l reads its 16 bytes at fragment*1024 + 16 l), term q in {hi, mid, lo}:
+// Packed parameter block (built by rdv_policy_create, copied to LDS by every workgroup).  fp16 section: weight FRAGMENTS of
+// 64 lanes x 8 fp16 (1 KiB; lane l reads its 16 bytes at fragment*1024 + 16 l), term q in {hi, lo} of w * 2^s_layer:
 //   layer 1, fragment (q*2 + mt)*2 + s      : lane (r, h), element j = W1_q[32 mt + r][16 s + 8 h + j]            (k >= 17: 0)
-//   layer 2, fragment 12 + (q*2 + mt)*4 + ks: lane (r, h), element j = W2_q[32 mt + r][perm(ks, h, j)]
-//   head,    fragment 36 + q*4 + ks         : lane (r, h), element j = W3_q[r][perm(ks, h, j)]                    (r >= 6: 0)
+//   layer 2, fragment  8 + (q*2 + mt)*4 + ks: lane (r, h), element j = W2_q[32 mt + r][perm(ks, h, j)]
+//   head,    fragment 24 + q*4 + ks         : lane (r, h), element j = W3_q[r][perm(ks, h, j)]                    (r >= 6: 0)
 // with perm(ks, h, j) = 32 (ks>>1) + 16 (ks&1) + 8 (j>>2) + 4 h + (j&3), the feature that element j of lane half h of registers
 // 8 (ks&1) .. 8 (ks&1) + 7 of accumulator tile ks>>1 holds.  fp32 section: the biases in accumulator order
-// ([mt][h][e] -> feature 32 mt + (e&3) + 8 (e>>2) + 4 h), exp(log_std) and log_std (entries 6, 7 zero).
+// ([mt][h][e] -> feature 32 mt + (e&3) + 8 (e>>2) + 4 h), multiplied by the layer's accumulator scale 2^(10 + s_layer); exp(log_std)
+// and log_std (entries 6, 7 zero); then per layer the inverse scale 2^-(10 + s_layer) (kPolScale: [0] layer 1, [1] layer 2, [2] head).
+constexpr int kPolXShift = 10;                                   // activations and inputs enter the MFMAs times 2^10
 constexpr int kPolFragBytes = 64 * 16;
-constexpr int kPolW1Frag = 0, kPolW2Frag = 12, kPolW3Frag = 36, kPolFrags = 48;
-constexpr int kPolF32 = kPolFrags * kPolFragBytes / 4;           // float index of the fp32 section: 12288
+constexpr int kPolW1Frag = 0, kPolW2Frag = 8, kPolW3Frag = 24, kPolFrags = 32;
+constexpr int kPolF32 = kPolFrags * kPolFragBytes / 4;           // float index of the fp32 section: 8192
 constexpr int kPolB1 = kPolF32, kPolB2 = kPolB1 + 64, kPolB3 = kPolB2 + 64, kPolStd = kPolB3 + 32, kPolLogStd = kPolStd + 8,
-              kPolFloats = kPolLogStd + 8;                       // 12,472 floats = 49,888 B
+              kPolScale = kPolLogStd + 8, kPolFloats = kPolScale + 4;   // 8,372 floats = 33,488 B
 static_assert(kPolFloats % 4 == 0, "the parameter block is copied as float4");
 // standalone kernel: parameters | per wave: observation rows [32][17] | per wave: action rows [32][6]
 constexpr int kPolObsStage = kPolWaveEnvs * kPolIn, kPolActStage = kPolWaveEnvs * kPolOut;
-constexpr int kPolLdsBytes = (kPolFloats + (kPolBlock / 64) * (kPolObsStage + kPolActStage)) * 4;   // 73,440 B: two workgroups per CU
+constexpr int kPolLdsBytes = (kPolFloats + (kPolBlock / 64) * (kPolObsStage + kPolActStage)) * 4;   // 57,040 B: two workgroups per CU
 
 // tanh in fp32 as 1 - 2 / (2^(2 log2(e) x) + 1), two at a time: v_exp_f32 + v_rcp_f32 (1 ulp each) per value and one packed multiply,
 // add and fma per pair (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  On x itself, without |x| and copysign: the power underflows
 // to 0 for x << 0 (-> exactly -1) and overflows to inf for x >> 0 (-> exactly +1).  Absolute error <= ~2.5e-7 everywhere
 // (cancellation near 0 costs relative, not absolute, accuracy; what feeds the next layer's sums is the absolute error, the same size
-// as the rounding of an activation near 1).  Round 2: the |x| / copysign form cost a v_bfi_b32 per value and kept the multiply
-// unpacked; with both gone the rollout kernel's closed-loop step went from 10.26 to 9.22 us (tools/lib_ab_persist.py).
-__device__ __forceinline__ void tanh2_f32(float x0, float x1, float& t0, float& t1) {
+// as the rounding of an activation near 1).  The argument arrives as the scaled accumulator: `kexp` = 2 log2(e) * 2^-(10 + s_layer)
+// (the scale is a power of two: exact), and the result leaves times 2^10, ready for the next layer's split.
+__device__ __forceinline__ void tanh2_f32(float x0, float x1, float kexp, float& t0, float& t1) {
   const pol_f2 x = {x0, x1};
-  const pol_f2 y = x * 2.8853900817779268f;
+  const pol_f2 y = x * kexp;
   const pol_f2 e = {__builtin_amdgcn_exp2f(y.x), __builtin_amdgcn_exp2f(y.y)};
   const pol_f2 s1 = e + 1.0f;
   const pol_f2 r = {__builtin_amdgcn_rcpf(s1.x), __builtin_amdgcn_rcpf(s1.y)};
-  const pol_f2 t = __builtin_elementwise_fma(pol_f2{-2.0f, -2.0f}, r, pol_f2{1.0f, 1.0f});
+  constexpr float one = (float)(1 << kPolXShift);
+  const pol_f2 t = __builtin_elementwise_fma(pol_f2{-2.0f * one, -2.0f * one}, r, pol_f2{one, one});
   t0 = t.x; t1 = t.y;
 }
 
@@ -90,38 +100,31 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// x[j] = hi[j] + mid[j] + lo[j] to 24 bits; each subtraction is exact in fp32.  (Written on 2-vectors — packed converts, packed subtracts,
-// 56 instructions fewer per wave — the standalone actor gains 1 % and the rollout kernel LOSES 6 %, 9.26 -> 9.87 us per step: there the
-// order in which the scheduler interleaves this with the dependent MFMA chains matters more than the count.  Kept scalar.)
-__device__ __forceinline__ void split3(const float (&x)[8], bf16x8 (&t)[3]) {
+// x[j] = hi[j] + lo[j] to 22 bits (x already scaled: |x| < 65504); the subtraction is exact in fp32
+__device__ __forceinline__ void split2(const float (&x)[8], f16x8 (&t)[2]) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const __bf16 hi = (__bf16)x[j];
+    const _Float16 hi = (_Float16)x[j];
     const float r1 = x[j] - (float)hi;
-    const __bf16 mid = (__bf16)r1;
-    const float r2 = r1 - (float)mid;
-    t[0][j] = hi; t[1][j] = mid; t[2][j] = (__bf16)r2;
+    t[0][j] = hi; t[1][j] = (_Float16)r1;
   }
 }
 
-// d += A . B for one 16-wide k-step, A (weights) and B (activations) given as their three bf16 terms: the six leading products,
+// d += A . B for one 16-wide k-step, A (weights) and B (activations) given as their two fp16 terms: the three leading products,
 // smallest first
-__device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 d) {
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], d, 0, 0, 0);
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], d, 0, 0, 0);
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], d, 0, 0, 0);
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], d, 0, 0, 0);
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], d, 0, 0, 0);
-  d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], d, 0, 0, 0);
+__device__ __forceinline__ f32x16 mfma3(const f16x8 (&a)[2], const f16x8 (&b)[2], f32x16 d) {
+  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[1], b[0], d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[1], d, 0, 0, 0);
+  d = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[0], b[0], d, 0, 0, 0);
   return d;
 }
 
 // One layer Y = W . X (+ bias) for the wave's 32 envs: MT row tiles of 32 output features, KS k-steps of 16 input features.
-// xb[ks]: the B fragments (three bf16 terms) of the input; frag0: index of the layer's first weight fragment, laid out
-// [q][mt][ks]; biasp: [mt][h][16] in accumulator order.
+// xb[ks]: the B fragments (two fp16 terms) of the input; frag0: index of the layer's first weight fragment, laid out
+// [q][mt][ks]; biasp: [mt][h][16] in accumulator order (scaled).  The accumulators come out times 2^(10 + s_layer).
 template <int MT, int KS>
-__device__ __forceinline__ void layer(const float* w, int frag0, const float* biasp, const bf16x8 (&xb)[KS][3], int lane, f32x16 (&d)[MT]) {
-  const bf16x8* wf = reinterpret_cast<const bf16x8*>(w) + lane;
+__device__ __forceinline__ void layer(const float* w, int frag0, const float* biasp, const f16x8 (&xb)[KS][2], int lane, f32x16 (&d)[MT]) {
+  const f16x8* wf = reinterpret_cast<const f16x8*>(w) + lane;
   const int h = lane >> 5;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -135,22 +138,22 @@ __device__ __forceinline__ void layer(const float* w, int frag0, const float* bi
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 a[3];
+      f16x8 a[2];
 #pragma unroll
-      for (int q = 0; q < 3; ++q) a[q] = wf[(frag0 + (q * MT + mt) * KS + ks) * 64];
-      d[mt] = mfma6(a, xb[ks], d[mt]);
+      for (int q = 0; q < 2; ++q) a[q] = wf[(frag0 + (q * MT + mt) * KS + ks) * 64];
+      d[mt] = mfma3(a, xb[ks], d[mt]);
     }
 }
 
-// tanh of an accumulator tile, split into the B fragments of the next layer's k-steps 2 t, 2 t + 1 (registers 0..7 and 8..15)
-__device__ __forceinline__ void activate(const f32x16& d, bf16x8 (&lo_step)[3], bf16x8 (&hi_step)[3]) {
+// tanh of a (scaled) accumulator tile, split into the B fragments of the next layer's k-steps 2 t, 2 t + 1 (registers 0..7 and 8..15)
+__device__ __forceinline__ void activate(const f32x16& d, float kexp, f16x8 (&lo_step)[2], f16x8 (&hi_step)[2]) {
   float x[8];
 #pragma unroll
-  for (int j = 0; j < 8; j += 2) tanh2_f32(d[j], d[j + 1], x[j], x[j + 1]);
-  split3(x, lo_step);
+  for (int j = 0; j < 8; j += 2) tanh2_f32(d[j], d[j + 1], kexp, x[j], x[j + 1]);
+  split2(x, lo_step);
 #pragma unroll
-  for (int j = 0; j < 8; j += 2) tanh2_f32(d[8 + j], d[9 + j], x[j], x[j + 1]);
-  split3(x, hi_step);
+  for (int j = 0; j < 8; j += 2) tanh2_f32(d[8 + j], d[9 + j], kexp, x[j], x[j + 1]);
+  split2(x, hi_step);
 }
 
 // The actor for the wave's 32 envs.  `rows`: LDS, the wave's observations [32][17] (stride 17).  Lane (r = l & 31, h = l >> 5) gets
@@ -158,31 +161,37 @@ __device__ __forceinline__ void activate(const f32x16& d, bf16x8 (&lo_step)[3], 
 __device__ __forceinline__ void actor_means(const float* w, const float* rows, int lane, float (&mean)[4]) {
   const int r = lane & 31, h = lane >> 5;
   const float* row = rows + r * kPolIn;
-  bf16x8 x0[2][3];
+  constexpr float xs = (float)(1 << kPolXShift), xmax = 63.0f * xs;       // inputs times 2^10, clamped into fp16's range
+  auto in = [&](float v) { const float c = __builtin_amdgcn_fmed3f(v * xs, -xmax, xmax); return v != v ? v : c; };   // NaN stays NaN (as in PyTorch)
+  f16x8 x0[2][2];
   {
     float x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) x[j] = row[8 * h + j];            // k-step 0: features 8h + j
-    split3(x, x0[0]);
-    const float last = row[16];
+    for (int j = 0; j < 8; ++j) x[j] = in(row[8 * h + j]);         // k-step 0: features 8h + j
+    split2(x, x0[0]);
+    const float last = in(row[16]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) x[j] = 0.0f;
     x[0] = h == 0 ? last : 0.0f;                                    // k-step 1: feature 16 only (17 inputs, padded to 32)
-    split3(x, x0[1]);
+    split2(x, x0[1]);
   }
+  constexpr float two_log2e = 2.8853900817779268f;
   f32x16 d1[2];
   layer<2, 2>(w, kPolW1Frag, w + kPolB1, x0, lane, d1);            // 17 -> 64
-  bf16x8 x1[4][3];
-  activate(d1[0], x1[0], x1[1]);
-  activate(d1[1], x1[2], x1[3]);
+  f16x8 x1[4][2];
+  const float k1 = two_log2e * w[kPolScale + 0];
+  activate(d1[0], k1, x1[0], x1[1]);
+  activate(d1[1], k1, x1[2], x1[3]);
   f32x16 d2[2];
   layer<2, 4>(w, kPolW2Frag, w + kPolB2, x1, lane, d2);            // 64 -> 64
-  bf16x8 x2[4][3];
-  activate(d2[0], x2[0], x2[1]);
-  activate(d2[1], x2[2], x2[3]);
+  f16x8 x2[4][2];
+  const float k2 = two_log2e * w[kPolScale + 1];
+  activate(d2[0], k2, x2[0], x2[1]);
+  activate(d2[1], k2, x2[2], x2[3]);
   f32x16 d3[1];
   layer<1, 4>(w, kPolW3Frag, w + kPolB3, x2, lane, d3);            // 64 -> 6 (rows 6..31 of the tile have zero weights)
-  mean[0] = d3[0][0]; mean[1] = d3[0][1]; mean[2] = d3[0][2]; mean[3] = d3[0][3];   // rows (e & 3) + 4 h
+  const float s3 = w[kPolScale + 2];                                // exact power of two
+  mean[0] = d3[0][0] * s3; mean[1] = d3[0][1] * s3; mean[2] = d3[0][2] * s3; mean[3] = d3[0][3] * s3;   // rows (e & 3) + 4 h
 }
 
 // Exploration noise of this lane's action components: Philox4x32-10 keyed by (seed, global env id, counter); block 0 gives the normals

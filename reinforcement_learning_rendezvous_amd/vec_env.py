@@ -128,6 +128,15 @@ class RendezvousVecEnv(_VecEnvBase):
             h = self._host.numpy()
             self._h_obs, self._h_rew, self._h_code = h[: n * 17].reshape(n, 17), h[n * 17: n * 18], h[n * 18:]
             self._fin_host = torch.empty((n, 19), dtype=torch.float32)          # rows of finished envs: terminal obs | return | length
+            # device side of that second message, allocated ONCE at its largest size: the number of finished envs changes every step,
+            # and fresh `index_select` / `cat` results of ever new sizes sent the caching allocator to hipMalloc now and then — the
+            # 4-8 ms outlier steps of round 2's `vecenv_numpy_boundary` (p99 against a 1.4 ms median; not the garbage collector: bench.py
+            # times its pauses beside the steps)
+            self._sel_dev = torch.empty(n, dtype=torch.int64, device=dev)
+            self._fin_dev = torch.empty((n, 19), dtype=torch.float32, device=dev)
+            self._g_obs = torch.empty((n, 17), dtype=torch.float32, device=dev)
+            self._g_ret = torch.empty(n, dtype=torch.float32, device=dev)
+            self._g_len = torch.empty(n, dtype=torch.int32, device=dev)
 
     def step_wait(self):
         b = self.batch
@@ -151,11 +160,16 @@ class RendezvousVecEnv(_VecEnvBase):
             # ... and the rows of the finished envs (terminal observation, episode return, length) as a second, small one: gathered on
             # the device, ~5 % of the envs per step with random actions.  The dicts are built from Python lists (tolist), not NumPy
             # scalars: this loop is the floor of the SB3 boundary (~0.45 us per finished env).
-            sel = torch.from_numpy(idx).to(b.device)
             k = idx.size
+            sel = self._sel_dev[:k]
+            sel.copy_(torch.from_numpy(idx))
+            torch.index_select(b.terminal_obs, 0, sel, out=self._g_obs[:k])
+            torch.index_select(b.episode_return, 0, sel, out=self._g_ret[:k])
+            torch.index_select(b.episode_length, 0, sel, out=self._g_len[:k])
+            dev_rows = self._fin_dev[:k]
+            dev_rows[:, :17].copy_(self._g_obs[:k]); dev_rows[:, 17].copy_(self._g_ret[:k]); dev_rows[:, 18].copy_(self._g_len[:k])
             fin = self._fin_host[:k]
-            fin.copy_(torch.cat([b.terminal_obs.index_select(0, sel), b.episode_return.index_select(0, sel).unsqueeze(1),
-                                 b.episode_length.index_select(0, sel).to(torch.float32).unsqueeze(1)], dim=1))
+            fin.copy_(dev_rows)
             packed = fin.numpy()
             t_obs = packed[:, :17].copy()
             ep_r, ep_l = packed[:, 17].tolist(), packed[:, 18].astype(np.int64).tolist()
