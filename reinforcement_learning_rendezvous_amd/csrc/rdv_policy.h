@@ -100,13 +100,18 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// x[j] = hi[j] + lo[j] to 22 bits (x already scaled: |x| < 65504); the subtraction is exact in fp32
+// x[j] = hi[j] + lo[j] to 22 bits (x already scaled: |x| < 65504); the subtraction is exact in fp32.  Two values at a time, so that
+// the conversions are the packed ones (v_cvt_pk_f16_f32) and the subtraction one v_pk_add_f32: 5 instructions per pair (written value by
+// value the compiler converted every hi twice — once for the residual, once into the pair — 8 per pair).
+typedef _Float16 pol_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(const float (&x)[8], f16x8 (&t)[2]) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const _Float16 hi = (_Float16)x[j];
-    const float r1 = x[j] - (float)hi;
-    t[0][j] = hi; t[1][j] = (_Float16)r1;
+  for (int j = 0; j < 8; j += 2) {
+    const pol_f2 v = {x[j], x[j + 1]};
+    const pol_h2 hi = __builtin_convertvector(v, pol_h2);
+    const pol_f2 r = v - __builtin_convertvector(hi, pol_f2);
+    const pol_h2 lo = __builtin_convertvector(r, pol_h2);
+    t[0][j] = hi.x; t[0][j + 1] = hi.y; t[1][j] = lo.x; t[1][j + 1] = lo.y;
   }
 }
 
