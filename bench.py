@@ -408,10 +408,12 @@ def main():
                 pauses.append((info["generation"], time.perf_counter() - t_gc[0], len(per)))
         per = []
         gc.callbacks.append(on_gc)
+        vec._trace = phases = []
         for k_ in range(200):
             p0 = time.perf_counter()
             vec.step(a_np[k_ % 4])
             per.append(time.perf_counter() - p0)
+        vec._trace = None
         gc.callbacks.remove(on_gc)
         gc_in_step = [0.0] * len(per)
         for gen_, dur_, k_ in pauses:
@@ -424,6 +426,9 @@ def main():
                                         "ms_per_step": {"mean": sum(per) / len(per) * 1e3, "median": order[len(per) // 2] * 1e3,
                                                         "p90": order[int(len(per) * 0.9)] * 1e3, "p99": order[int(len(per) * 0.99)] * 1e3,
                                                         "max": order[-1] * 1e3},
+                                        "phases_ms": {"names": ["kernels + packed D2H (synchronises)", "done mask", "finished rows: gather + D2H", "host unpack + infos dicts"],
+                                                      "median_step": [sorted(p_[j] for p_ in phases)[len(phases) // 2] * 1e3 for j in range(4)],
+                                                      "slowest_step": [x_ * 1e3 for x_ in phases[worst]]},
                                         "gc": {"collections_by_generation": [sum(1 for g_, _, _ in pauses if g_ == j) for j in range(3)],
                                                "longest_pause_ms": max([d_ for _, d_, _ in pauses], default=0.0) * 1e3,
                                                "gc_ms_inside_the_slowest_step": gc_in_step[worst] * 1e3,

@@ -553,8 +553,9 @@ constexpr int kSplitBlock = 512;     // 8 waves
 //  - so the work itself would have to go: the step waves post, a quarter into the transition, which episodes CERTAINLY end (time limit,
 //    bubble) and the service waves reset only those, by part, beside the rest of the transition (step_kernel_hint): 7.99 us.  14 % of
 //    this workload's ends are attitude-error ends, known only after the chaser's attitude step — 83 % of the workgroups have one per
-//    step and pay a third barrier — and a dozen-lane by-part pass takes 4,400 cycles, not 1,200: after the kernel's first global
-//    store the compiler fetches every parameter field with a uniform-address VECTOR load (profiles/r03_split_hint_stamps.txt).
+//    step and pay a third barrier — and a dozen-lane by-part pass takes ~4,400 cycles beside the rest of the transition, not the
+//    ~1,200 its ~300 instructions suggest: its Philox blocks are quarter-rate integer multiplies on the same VALU the step wave is
+//    saturating (profiles/r03_split_hint_stamps.txt).
 template <typename ST>
 __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {

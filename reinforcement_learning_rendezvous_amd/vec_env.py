@@ -98,6 +98,7 @@ class RendezvousVecEnv(_VecEnvBase):
         self.copy_outputs = bool(copy_outputs)
         self._infos = [{} for _ in range(self.num_envs)]
         self._dirty = []
+        self._trace = None
         self._t_start = time.time()
         if gc_freeze:
             import gc
@@ -140,11 +141,16 @@ class RendezvousVecEnv(_VecEnvBase):
 
     def step_wait(self):
         b = self.batch
+        tr = self._trace          # None, or a list that receives one tuple of phase times (s) per step (bench.py: which phase the rare slow step spends its time in)
+        if tr is not None:
+            t0 = time.perf_counter()
         b.step(self._actions)
         self._host_buffers()
         # obs | reward | done_reason (0 = not done; bits as in RdvStepOut) leave the device as ONE message ...
         self._pack_obs.copy_(b.obs); self._pack_rew.copy_(b.reward); self._pack_code.copy_(b.done_reason)
         self._host.copy_(self._pack)                                             # (synchronises)
+        if tr is not None:
+            t1 = time.perf_counter()
         codes_f = self._h_code
         done_h = codes_f != 0.0
         if self.copy_outputs:
@@ -156,6 +162,8 @@ class RendezvousVecEnv(_VecEnvBase):
             infos[i] = {}
         self._dirty = []
         idx = np.flatnonzero(done_h)
+        if tr is not None:
+            t2 = t3 = time.perf_counter()
         if idx.size:
             # ... and the rows of the finished envs (terminal observation, episode return, length) as a second, small one: gathered on
             # the device, ~5 % of the envs per step with random actions.  The dicts are built from Python lists (tolist), not NumPy
@@ -170,6 +178,8 @@ class RendezvousVecEnv(_VecEnvBase):
             dev_rows[:, :17].copy_(self._g_obs[:k]); dev_rows[:, 17].copy_(self._g_ret[:k]); dev_rows[:, 18].copy_(self._g_len[:k])
             fin = self._fin_host[:k]
             fin.copy_(dev_rows)
+            if tr is not None:
+                t3 = time.perf_counter()
             packed = fin.numpy()
             t_obs = packed[:, :17].copy()
             ep_r, ep_l = packed[:, 17].tolist(), packed[:, 18].astype(np.int64).tolist()
@@ -190,6 +200,9 @@ class RendezvousVecEnv(_VecEnvBase):
                           str(t_end).rjust(4) + " | " + _END_REASONS[code & 7].center(8) +
                           " | " + ("Collided" if code & 16 else " "))
             self._dirty = idx_list
+        if tr is not None:
+            t4 = time.perf_counter()
+            tr.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))     # kernels + packed D2H | masks | finished rows: gather + D2H | host unpack + infos dicts
         return obs_h, rew_h, done_h, self._infos
 
     def step(self, actions):
