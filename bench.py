@@ -426,7 +426,7 @@ def main():
                                         "ms_per_step": {"mean": sum(per) / len(per) * 1e3, "median": order[len(per) // 2] * 1e3,
                                                         "p90": order[int(len(per) * 0.9)] * 1e3, "p99": order[int(len(per) * 0.99)] * 1e3,
                                                         "max": order[-1] * 1e3},
-                                        "phases_ms": {"names": ["kernels + packed D2H (synchronises)", "done mask", "finished rows: gather + D2H", "host unpack + infos dicts"],
+                                        "phases_ms": {"names": ["step kernel + the message's D2H (synchronises)", "done mask", "finished rows picked on the host", "infos dicts"],
                                                       "median_step": [sorted(p_[j] for p_ in phases)[len(phases) // 2] * 1e3 for j in range(4)],
                                                       "slowest_step": [x_ * 1e3 for x_ in phases[worst]]},
                                         "gc": {"collections_by_generation": [sum(1 for g_, _, _ in pauses if g_ == j) for j in range(3)],
@@ -434,8 +434,9 @@ def main():
                                                "gc_ms_inside_the_slowest_step": gc_in_step[worst] * 1e3,
                                                "slowest_step_ms": per[worst] * 1e3},
                                         "note": "RendezvousVecEnv.step with NumPy actions in, NumPy obs/reward/done + infos out (PCIe-inclusive; "
-                                                "never the bench value): one packed D2H message + the rows of the finished envs; ~70 % of it "
-                                                "is building the infos dicts of the ~3,500 finished envs per step (profiles/r02_vecenv_profile.txt); "
+                                                "never the bench value): ONE fixed-size D2H message per step that rdv_step writes in place (obs, reward, "
+                                                "terminal rows, episode return / length, reasons); ~70 % of a step is building the infos dicts of the "
+                                                "~3,500 finished envs (`phases_ms`); "
                                                 "`gc` shows how much of the slowest step was the interpreter's garbage collector"}
         env.reset()
 

@@ -117,27 +117,30 @@ class RendezvousVecEnv(_VecEnvBase):
         self._actions = torch.from_numpy(np.ascontiguousarray(a)).to(self.batch.device)
 
     def _host_buffers(self):
-        """One packed device buffer [obs N x 17 | reward N | code N] and ONE reused (pageable) host array it is copied into per
-        step: a fresh `.cpu()` result per array costs an allocation and ~2,500 first-touch page faults per step at 65,536 envs."""
+        """ONE fixed-size message per step.  All per-env outputs of a step — obs [N,17], reward [N], terminal_obs [N,17],
+        episode_return [N], episode_length [N], done_reason [N], done [N] — are views of one contiguous device buffer that the engine
+        is told to use as its step outputs (``bind_outputs``): ``rdv_step`` writes the message in place (no pack kernels) and one
+        device -> host copy of constant size moves it into ONE reused host buffer (a fresh ``.cpu()`` result per array costs an
+        allocation and ~2,500 first-touch page faults per step at 65,536 envs).  Round 2 sent the rows of the finished envs as a second,
+        variable-size message (index upload + gather + download): its size changed every step, and every so often the runtime's staging
+        of a not-yet-seen size stalled a step for 4-8 ms — bench.py's ``phases_ms`` caught the slowest step of 200 spending 5.7 of its
+        6.2 ms there.  The terminal rows of ALL envs ride along instead (+4.7 MB per step at 65,536 envs, ~0.1 ms of PCIe): the host
+        picks the finished ones with one fancy index."""
         if self._pack is None:
-            n, dev = self.num_envs, self.batch.device
-            self._pack = torch.empty(n * 19, dtype=torch.float32, device=dev)
-            self._pack_obs = self._pack[: n * 17].view(n, 17)
-            self._pack_rew = self._pack[n * 17: n * 18]
-            self._pack_code = self._pack[n * 18:]
-            self._host = torch.empty(n * 19, dtype=torch.float32)
-            h = self._host.numpy()
-            self._h_obs, self._h_rew, self._h_code = h[: n * 17].reshape(n, 17), h[n * 17: n * 18], h[n * 18:]
-            self._fin_host = torch.empty((n, 19), dtype=torch.float32)          # rows of finished envs: terminal obs | return | length
-            # device side of that second message, allocated ONCE at its largest size: the number of finished envs changes every step,
-            # and fresh `index_select` / `cat` results of ever new sizes sent the caching allocator to hipMalloc now and then — the
-            # 4-8 ms outlier steps of round 2's `vecenv_numpy_boundary` (p99 against a 1.4 ms median; not the garbage collector: bench.py
-            # times its pauses beside the steps)
-            self._sel_dev = torch.empty(n, dtype=torch.int64, device=dev)
-            self._fin_dev = torch.empty((n, 19), dtype=torch.float32, device=dev)
-            self._g_obs = torch.empty((n, 17), dtype=torch.float32, device=dev)
-            self._g_ret = torch.empty(n, dtype=torch.float32, device=dev)
-            self._g_len = torch.empty(n, dtype=torch.int32, device=dev)
+            from .sharding import _PlanarMessage
+            n, b = self.num_envs, self.batch
+            msg = _PlanarMessage([("obs", (n, 17), torch.float32), ("reward", (n,), torch.float32), ("terminal_obs", (n, 17), torch.float32),
+                                  ("episode_return", (n,), torch.float32), ("episode_length", (n,), torch.int32),
+                                  ("done_reason", (n,), torch.uint8), ("done", (n,), torch.uint8)], b.device)
+            self._msg = msg
+            self._bound = hasattr(b, "bind_outputs")
+            if self._bound:
+                b.bind_outputs(**msg.views)                               # the HIP engine writes the message itself
+            self._pack = msg.flat
+            self._host = torch.empty(msg.nbytes, dtype=torch.uint8)       # pageable, reused
+            hv = msg.views_of(self._host)
+            self._h = {k: v.numpy() for k, v in hv.items()}
+            self._h_obs, self._h_rew = self._h["obs"], self._h["reward"]
 
     def step_wait(self):
         b = self.batch
@@ -146,13 +149,16 @@ class RendezvousVecEnv(_VecEnvBase):
             t0 = time.perf_counter()
         b.step(self._actions)
         self._host_buffers()
-        # obs | reward | done_reason (0 = not done; bits as in RdvStepOut) leave the device as ONE message ...
-        self._pack_obs.copy_(b.obs); self._pack_rew.copy_(b.reward); self._pack_code.copy_(b.done_reason)
-        self._host.copy_(self._pack)                                             # (synchronises)
+        if not self._bound:         # engines without bind_outputs (the CPU-oracle-backed test engine): copy the arrays in
+            v = self._msg.views
+            v["obs"].copy_(b.obs); v["reward"].copy_(b.reward); v["terminal_obs"].copy_(b.terminal_obs)
+            v["episode_return"].copy_(b.episode_return); v["episode_length"].copy_(b.episode_length); v["done_reason"].copy_(b.done_reason)
+        self._host.copy_(self._pack)                                             # ONE message, constant size (synchronises)
         if tr is not None:
             t1 = time.perf_counter()
-        codes_f = self._h_code
-        done_h = codes_f != 0.0
+        h = self._h
+        codes_u8 = h["done_reason"]                                              # 0 = not done; bits as in RdvStepOut
+        done_h = codes_u8 != 0
         if self.copy_outputs:
             obs_h, rew_h = self._h_obs.copy(), self._h_rew.copy()
         else:
@@ -165,25 +171,14 @@ class RendezvousVecEnv(_VecEnvBase):
         if tr is not None:
             t2 = t3 = time.perf_counter()
         if idx.size:
-            # ... and the rows of the finished envs (terminal observation, episode return, length) as a second, small one: gathered on
-            # the device, ~5 % of the envs per step with random actions.  The dicts are built from Python lists (tolist), not NumPy
-            # scalars: this loop is the floor of the SB3 boundary (~0.45 us per finished env).
-            k = idx.size
-            sel = self._sel_dev[:k]
-            sel.copy_(torch.from_numpy(idx))
-            torch.index_select(b.terminal_obs, 0, sel, out=self._g_obs[:k])
-            torch.index_select(b.episode_return, 0, sel, out=self._g_ret[:k])
-            torch.index_select(b.episode_length, 0, sel, out=self._g_len[:k])
-            dev_rows = self._fin_dev[:k]
-            dev_rows[:, :17].copy_(self._g_obs[:k]); dev_rows[:, 17].copy_(self._g_ret[:k]); dev_rows[:, 18].copy_(self._g_len[:k])
-            fin = self._fin_host[:k]
-            fin.copy_(dev_rows)
+            # the rows of the finished envs (~5 % of the envs per step with random actions), picked out of the message on the host.
+            # The dicts are built from Python lists (tolist), not NumPy scalars: this loop is the floor of the SB3 boundary
+            # (~0.3 us per finished env).
+            t_obs = h["terminal_obs"][idx]                                       # fancy index: a copy, [k,17]
+            ep_r, ep_l = h["episode_return"][idx].tolist(), h["episode_length"][idx].tolist()
+            codes = codes_u8[idx].tolist()
             if tr is not None:
                 t3 = time.perf_counter()
-            packed = fin.numpy()
-            t_obs = packed[:, :17].copy()
-            ep_r, ep_l = packed[:, 17].tolist(), packed[:, 18].astype(np.int64).tolist()
-            codes = codes_f[idx].astype(np.int64).tolist()
             now = round(time.time() - self._t_start, 6)
             idx_list = idx.tolist()
             reasons = _END_REASONS
@@ -202,7 +197,7 @@ class RendezvousVecEnv(_VecEnvBase):
             self._dirty = idx_list
         if tr is not None:
             t4 = time.perf_counter()
-            tr.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))     # kernels + packed D2H | masks | finished rows: gather + D2H | host unpack + infos dicts
+            tr.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))     # kernel + the message's D2H | done mask | finished rows picked | infos dicts
         return obs_h, rew_h, done_h, self._infos
 
     def step(self, actions):

@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
+from reinforcement_learning_rendezvous_amd import _native
+if os.environ.get("RDV_AB_LIB"):                      # another build of the library (A/B: tools/lib_ab*.py do the same)
+    _native.LIB_PATH, _native.STRICT = os.environ["RDV_AB_LIB"], False
 from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
 from reinforcement_learning_rendezvous_amd.params import make_params
 

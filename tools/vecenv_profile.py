@@ -38,42 +38,18 @@ for k in range(20):
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
 
-# ---- phase breakdown: the body of step_async / step_wait replayed with a timer (and a device sync) after each phase
-import torch
-from reinforcement_learning_rendezvous_amd.vec_env import _END_REASONS
-b = vec.batch
-vec._host_buffers()
-names = ["H2D actions", "step + pack kernels", "D2H packed", "mask + flatnonzero", "finished rows: gather + D2H", "host unpack (copy, tolist)", "infos dicts"]
-acc = np.zeros(len(names))
-K = 40
+# ---- phase breakdown: the env's own per-step phase timer (RendezvousVecEnv._trace)
+vec._trace = ph = []
+K = 100
 for k in range(K):
-    ts = [time.perf_counter()]
-    a = torch.from_numpy(acts[k % 8]).to(b.device); torch.cuda.synchronize(); ts.append(time.perf_counter())
-    b.step(a)
-    vec._pack_obs.copy_(b.obs); vec._pack_rew.copy_(b.reward); vec._pack_code.copy_(b.done_reason); torch.cuda.synchronize(); ts.append(time.perf_counter())
-    vec._host.copy_(vec._pack); ts.append(time.perf_counter())
-    done_h = vec._h_code != 0.0
-    idx = np.flatnonzero(done_h); ts.append(time.perf_counter())
-    sel = torch.from_numpy(idx).to(b.device)
-    fin = vec._fin_host[:idx.size]
-    fin.copy_(torch.cat([b.terminal_obs.index_select(0, sel), b.episode_return.index_select(0, sel).unsqueeze(1),
-                         b.episode_length.index_select(0, sel).to(torch.float32).unsqueeze(1)], dim=1)); ts.append(time.perf_counter())
-    packed = fin.numpy()
-    t_obs = packed[:, :17].copy()
-    ep_r, ep_l = packed[:, 17].tolist(), packed[:, 18].astype(np.int64).tolist()
-    codes = vec._h_code[idx].astype(np.int64).tolist()
-    idx_list = idx.tolist(); ts.append(time.perf_counter())
-    infos = [{} for _ in range(0)]
-    out = {}
-    for i, row, r, l, c in zip(idx_list, t_obs, ep_r, ep_l, codes):
-        out[i] = {"terminal_observation": row, "episode": {"r": r, "l": l, "t": 0.0}, "end_reason": _END_REASONS[c & 7], "collided": (c & 16) != 0,
-                  "success": (c & 32) != 0}
-    ts.append(time.perf_counter())
-    acc += np.diff(ts)
-print(f"phase breakdown (ms per step, {K} steps, ~{idx.size} finished envs per step):")
-for nm, v in zip(names, acc / K * 1e3):
-    print(f"   {nm:32s} {v:6.3f}")
-print(f"   {'sum':32s} {acc.sum() / K * 1e3:6.3f}")
+    vec.step(acts[k % 8])
+vec._trace = None
+ph = np.array(ph) * 1e3
+names = ["step kernel + the message's D2H (synchronises)", "done mask", "finished rows picked on the host", "infos dicts"]
+print(f"phase breakdown (ms per step, {K} steps): mean | median | max")
+for j, nm in enumerate(names):
+    print(f"   {nm:50s} {ph[:, j].mean():6.3f} {np.median(ph[:, j]):6.3f} {ph[:, j].max():6.3f}")
+print(f"   {'sum':50s} {ph.sum(axis=1).mean():6.3f}")
 
 # ---- rare slow steps: 400 steps, the slowest ones and where they fall (collector on, then off)
 for label, off in (("collector on", False), ("collector off", True)):
