@@ -538,15 +538,6 @@ __device__ __forceinline__ void reset_uniforms(uint64_t seed, uint64_t env_id, u
   u[6 * j + 3] = u21(c2 & 0x1FFFFFu); u[6 * j + 4] = u21(((c2 >> 21) | (c3 << 11)) & 0x1FFFFFu); u[6 * j + 5] = u21((c3 >> 10) & 0x1FFFFFu);
 }
 
-#ifdef RDV_EXP_U16
-__device__ __forceinline__ double u16f(uint32_t field) { return ((double)field + 0.5) * (1.0 / 65536.0); }
-__device__ __forceinline__ void reset_uniforms8(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t j, double* u) {
-  uint32_t c0 = (uint32_t)env_id, c1 = (uint32_t)(env_id >> 32), c2 = episode, c3 = j;
-  philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
-  u[8 * j + 0] = u16f(c0 & 0xFFFFu); u[8 * j + 1] = u16f(c0 >> 16); u[8 * j + 2] = u16f(c1 & 0xFFFFu); u[8 * j + 3] = u16f(c1 >> 16);
-  u[8 * j + 4] = u16f(c2 & 0xFFFFu); u[8 * j + 5] = u16f(c2 >> 16); u[8 * j + 6] = u16f(c3 & 0xFFFFu); u[8 * j + 7] = u16f(c3 >> 16);
-}
-#endif
 // Which part of a new initial state a call computes.  The six sampled quantities of reset() are independent given their
 // uniforms (only wc needs R(qc) and wt needs R(qt), :256, :258), so the preparation of a next-episode state can be shared out
 // over several waves, each running a short instruction stream over the same list of envs (prepared-state slots,
@@ -582,16 +573,10 @@ __device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_
   } else {
     // u[0..3] rc, u[4..7] vc, u[8..11] qc, u[12..15] wc, u[16..19] qt, u[20..23] wt; block j holds u[6j .. 6j+5]
     double u[24];
-#ifdef RDV_EXP_U16
-    if (do_rv) reset_uniforms8(seed, env_id, e.episode, 0, u);
-    if (do_c) reset_uniforms8(seed, env_id, e.episode, 1, u);
-    if (do_qt) reset_uniforms8(seed, env_id, e.episode, 2, u);
-#else
     if (do_rv) reset_uniforms(seed, env_id, e.episode, 0, u);
     if (do_rv || do_c) reset_uniforms(seed, env_id, e.episode, 1, u);
     if (do_c || do_qt) reset_uniforms(seed, env_id, e.episode, 2, u);
     if (do_qt) reset_uniforms(seed, env_id, e.episode, 3, u);
-#endif
     double dir[3], tmp[3], R[9];
     if (do_rv) {
       unit_vector(u[0], u[1], u[2], dir);                                   // :231
