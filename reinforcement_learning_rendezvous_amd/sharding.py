@@ -53,7 +53,7 @@ def _check_equal_shards(n_local, device, what):
         raise ValueError(f"{what} needs equally sized shards, got {got} (make the global env count a multiple of the number of ranks)")
 
 
-class _PlanarMessage:
+class PlanarMessage:
     """One contiguous byte buffer holding several arrays back to back (each 256-byte aligned): the message of a gather.  The arrays
     are VIEWS of it, so a kernel that is handed them as its outputs writes the message in place."""
 
@@ -94,7 +94,7 @@ class RolloutBufferGather:
         self.T, self.n = int(n_steps), int(n_local)
         _check_equal_shards(self.n, device, "RolloutBufferGather")
         T, n = self.T, self.n
-        self.msg = _PlanarMessage([("obs", (T, n, 17), torch.float32), ("actions", (T, n, 6), torch.float32),
+        self.msg = PlanarMessage([("obs", (T, n, 17), torch.float32), ("actions", (T, n, 6), torch.float32),
                                    ("reward", (T, n), torch.float32), ("log_prob", (T, n), torch.float32),
                                    ("done", (T, n), torch.uint8), ("last_obs", (n, 17), torch.float32)], device)
         self.local = self.msg.views
@@ -137,7 +137,7 @@ class RolloutGather:
         self.world, self.rank, self.dst, self.n = dist.get_world_size(), dist.get_rank(), int(dst), int(n_local)
         _check_equal_shards(self.n, device, "RolloutGather")
         n = self.n
-        self.msg = _PlanarMessage([("obs", (n, 17), torch.float32), ("reward", (n,), torch.float32), ("done", (n,), torch.uint8)], device)
+        self.msg = PlanarMessage([("obs", (n, 17), torch.float32), ("reward", (n,), torch.float32), ("done", (n,), torch.uint8)], device)
         self.local = self.msg.views
         self.message_bytes = self.msg.nbytes
         self.full = torch.zeros((self.world, self.msg.nbytes), dtype=torch.uint8, device=device) if self.rank == self.dst else None

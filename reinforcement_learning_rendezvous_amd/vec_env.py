@@ -127,9 +127,9 @@ class RendezvousVecEnv(_VecEnvBase):
         6.2 ms there.  The terminal rows of ALL envs ride along instead (+4.7 MB per step at 65,536 envs, ~0.1 ms of PCIe): the host
         picks the finished ones with one fancy index."""
         if self._pack is None:
-            from .sharding import _PlanarMessage
+            from .sharding import PlanarMessage
             n, b = self.num_envs, self.batch
-            msg = _PlanarMessage([("obs", (n, 17), torch.float32), ("reward", (n,), torch.float32), ("terminal_obs", (n, 17), torch.float32),
+            msg = PlanarMessage([("obs", (n, 17), torch.float32), ("reward", (n,), torch.float32), ("terminal_obs", (n, 17), torch.float32),
                                   ("episode_return", (n,), torch.float32), ("episode_length", (n,), torch.int32),
                                   ("done_reason", (n,), torch.uint8), ("done", (n,), torch.uint8)], b.device)
             self._msg = msg
