@@ -392,12 +392,13 @@ def main():
         vec = RendezvousVecEnv(n, engine=env)
         a_np = [r_.cpu().numpy() for r_ in ring[:4]]
         vec.reset()
-        for k_ in range(10):
+        for k_ in range(80):          # past the transient after reset(): all episodes start together, and their first ends come in bursts
             vec.step(a_np[k_ % 4])
-        # the slowest steps of this loop are the interpreter's garbage collector, not the boundary: every step allocates ~7,000 dicts
-        # (infos + their "episode" entries), so generation-0/1 collections run inside most steps and a generation-2 pass (which walks
-        # every live container, the 65,536 infos dicts included) lands in one step now and then.  The pauses are recorded beside the
-        # step times so that the line shows which is which.
+        # What a slow step of this loop is made of is recorded beside the step times: the interpreter's garbage-collector pauses (every
+        # step allocates ~7,000 dicts: generation-0/1 collections run inside most steps, a generation-2 pass now and then), the env's own
+        # phase timer, and the number of envs that finished in the step — the step time is linear in it (~0.3 us of dict building per
+        # finished env), and round 2's 8.5 ms outlier was a step of the post-reset transient in which several times the steady-state
+        # ~3,500 envs finished at once.
         import gc
         pauses, t_gc = [], [0.0]
 
@@ -428,7 +429,9 @@ def main():
                                                         "max": order[-1] * 1e3},
                                         "phases_ms": {"names": ["step kernel + the message's D2H (synchronises)", "done mask", "finished rows picked on the host", "infos dicts"],
                                                       "median_step": [sorted(p_[j] for p_ in phases)[len(phases) // 2] * 1e3 for j in range(4)],
-                                                      "slowest_step": [x_ * 1e3 for x_ in phases[worst]]},
+                                                      "slowest_step": [x_ * 1e3 for x_ in phases[worst][:4]]},
+                                        "finished_envs_per_step": {"median": sorted(p_[4] for p_ in phases)[len(phases) // 2],
+                                                                   "max": max(p_[4] for p_ in phases), "in_the_slowest_step": phases[worst][4]},
                                         "gc": {"collections_by_generation": [sum(1 for g_, _, _ in pauses if g_ == j) for j in range(3)],
                                                "longest_pause_ms": max([d_ for _, d_, _ in pauses], default=0.0) * 1e3,
                                                "gc_ms_inside_the_slowest_step": gc_in_step[worst] * 1e3,

@@ -608,15 +608,18 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     // The barrier comes HERE, as soon as the service waves have what they wait for (which envs ended, the observation rows), not at the
     // end of the step wave: the statistics, the per-env outputs and the stores of the step wave (~1.1 us) then run beside the service
     // waves' reset writes (~0.9 us) instead of in front of them (stamps: 5.7 -> ~5.0 us from the first wave's entry to the last exit).
+    // The state of the envs that go on is stored BEFORE the barrier (round 3): the step waves reach it ~700 cycles ahead of the service
+    // waves, and these 6 x 16-byte-per-lane stores drain inside that wait instead of after it (tools/lib_ab.py: 6.80 -> 6.73 us at
+    // 65,536 envs, 5.35 -> 5.29 at 16,384; moving the reward / done / terminal-row stores there as well loses: 6.89).  Reset lanes: service wave.
+    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+    if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);
     RDV_STAMP(3);
     __syncthreads();
     RDV_STAMP(4);
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
     store_step_outputs<true>(A, i, active, fin, r, e, obs_r);
-    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
     if (m_reset == 0ull) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
     RDV_STAMP(5);
-    if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);   // 6 x 16-byte-per-lane stores; reset lanes: service wave
     RDV_STAMP(6);
   } else {
     // ------------------------------------------------------------------ service waves

@@ -197,7 +197,7 @@ class RendezvousVecEnv(_VecEnvBase):
             self._dirty = idx_list
         if tr is not None:
             t4 = time.perf_counter()
-            tr.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3))     # kernel + the message's D2H | done mask | finished rows picked | infos dicts
+            tr.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, int(idx.size)))   # kernel + the message's D2H | done mask | finished rows picked | infos dicts | finished envs
         return obs_h, rew_h, done_h, self._infos
 
     def step(self, actions):
