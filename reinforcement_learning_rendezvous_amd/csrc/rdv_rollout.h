@@ -12,7 +12,7 @@
 //   - the current observations [256,17] and actions [256,6] are handed over through LDS; two workgroup barriers per step;
 //   - nothing is re-read from HBM between steps and there is no launch boundary: of the 19 us a policy_act + step pair takes
 //     at 65,536 envs, ~5 us are launch gaps and kernel entry/exit, and the state / observation round trips.
-// Phase A (actor waves): obs_t rows -> HBM; the actor of rdv_policy.h (bf16x3 MFMAs, register-resident), the sample from the noise
+// Phase A (actor waves): obs_t rows -> HBM; the actor of rdv_policy.h (two-term fp16 MFMAs, register-resident), the sample from the noise
 // drawn one phase earlier, clip -> LDS and HBM.
 // Phase B (env waves): transition, reward/done -> HBM, obs_{t+1} -> LDS.  A lane whose episode ended copies its prepared slot
 // (rdv_slots.h; the workgroup's 256 slots live in LDS during the launch) — no reset arithmetic in the env phase.  BESIDE phase B the
