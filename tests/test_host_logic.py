@@ -467,3 +467,31 @@ def test_vecenv_tensor_fast_path_and_batched_helpers():
     o2, r2, d2, _ = twin.step(a.numpy())
     np.testing.assert_array_equal(obs.numpy(), o2); np.testing.assert_array_equal(rew.numpy(), r2)
     np.testing.assert_array_equal(done.numpy().astype(bool), d2)
+
+
+def test_planar_message_views_are_aligned_disjoint_and_tile_the_buffer():
+    """sharding.PlanarMessage: the arrays of a gather / VecEnv message are views of ONE byte buffer, each starting on a 256-byte
+    boundary (rdv_step needs 16-byte aligned observation rows), none overlapping, also under a leading rank dimension."""
+    from reinforcement_learning_rendezvous_amd.sharding import PlanarMessage
+    n = 37          # odd sizes: every field needs its padding
+    fields = [("obs", (n, 17), torch.float32), ("reward", (n,), torch.float32), ("terminal_obs", (n, 17), torch.float32),
+              ("episode_length", (n,), torch.int32), ("done_reason", (n,), torch.uint8), ("done", (n,), torch.uint8)]
+    m = PlanarMessage(fields, torch.device("cpu"))
+    base = m.flat.data_ptr()
+    spans = []
+    for name, shape, dtype in fields:
+        v = m.views[name]
+        assert tuple(v.shape) == shape and v.dtype == dtype and v.is_contiguous()
+        off = v.data_ptr() - base
+        assert off % 256 == 0 and v.untyped_storage().data_ptr() == m.flat.untyped_storage().data_ptr()
+        spans.append((off, off + v.numel() * v.element_size()))
+    assert all(a[1] <= b[0] for a, b in zip(spans, spans[1:])) and spans[-1][1] <= m.nbytes and m.nbytes % 256 == 0
+    for k, (name, _, _) in enumerate(fields):      # writing one array touches no other
+        m.flat.zero_()
+        m.views[name].fill_(1)
+        assert all(int(m.views[o].sum()) == 0 for o, _, _ in fields if o != name)
+    full = torch.zeros((3, m.nbytes), dtype=torch.uint8)
+    g = m.views_of(full, lead=(3,))
+    g["reward"][1].fill_(2.5)
+    assert float(m.views_of(full[1])["reward"].sum()) == pytest.approx(2.5 * n) and float(g["reward"][0].sum()) == 0.0
+    assert g["obs"].shape == (3, n, 17) and g["obs"].untyped_storage().data_ptr() == full.untyped_storage().data_ptr()
