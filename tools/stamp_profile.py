@@ -24,8 +24,8 @@ def main():
     wpg = 4 * (1 + svc)
     lib = os.path.join(ROOT, "tools", "_stamps.so")
     src = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_hip.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DRDV_STAMPS",
-                           "-shared", "-o", lib, src])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DRDV_STAMPS"] + os.environ.get("RDV_EXTRA_FLAGS", "").split() +
+                          ["-shared", "-o", lib, src])
     import torch
     from reinforcement_learning_rendezvous_amd import _native
     _native.LIB_PATH = lib
