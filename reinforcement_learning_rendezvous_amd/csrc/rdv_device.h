@@ -22,7 +22,6 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
 
 namespace rdv {
 
@@ -369,15 +368,9 @@ __device__ __forceinline__ void derive_chaser(const DevParams& P, const Env& e, 
 template <bool kLazy>
 __device__ __forceinline__ void derive_target(const DevParams& P, const Env& e, Derived& d, double inv_dist) {
   double Rt[9];
-  double rd_l[3];
-#ifdef RDV_FAKE_NOTARGET
-  rd_l[0] = e.qt[0] * P.rd[0]; rd_l[1] = e.qt[1] * P.rd[1]; rd_l[2] = e.qt[2] * P.rd[2];
-  if (d.r2 <= P.lt2_koz || d.r2 < 0.0)
-#endif
   quat2mat(e.qt, Rt);
-#ifndef RDV_FAKE_NOTARGET
+  double rd_l[3];
   matvec(Rt, P.rd, rd_l);               // :460
-#endif
   const double dp[3] = {e.rc[0] - rd_l[0], e.rc[1] - rd_l[1], e.rc[2] - rd_l[2]};
   d.pos2 = sumsq3(dp);                  // :463
   const double inf = __builtin_huge_val();
@@ -682,13 +675,8 @@ struct StepResult {   // (the observation goes to the caller's sink: see observa
 };
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
-// `early(ends)`: optional hook, called once the chaser side is known (~40 % into the transition) with what the done test at the end
-// will find as far as it can be known there — time limit, bubble, attitude error; not Box.contains — so that a caller can have the
-// next episode's prepared state travelling from HBM while the rest of the transition computes (step_kernel_slots).  A hint only: the
-// test at the end decides.
-struct NoEarly { __device__ __forceinline__ void operator()(bool) const {} };
-template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink, typename Early = NoEarly>
-__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink, Early&& early = Early{}) {
+template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink>
+__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink) {
   const ST tag = ST(0);
   // :201-202, :333 need the action only through these two float32 sums: formed here, so that the six action registers die with the
   // impulses below instead of living to the end of the transition
@@ -724,19 +712,13 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   double inv_dist;
   derive_chaser(P, e, d, inv_dist);
   const double att = attitude_error_of(P, d.k_att);
-  if constexpr (!std::is_same<typename std::decay<Early>::type, NoEarly>::value) {
-    const double nb = canon(fmax(e.bubble - P.bubble_decrease_rate, P.bubble_min), tag), nb2 = nb * nb;   // the expressions of :196-198, :369 below
-    early(e.k + 1 >= P.k_time || d.r2 > nb2 * (1.0 + 1e-15) || d.k_att <= P.ka_done_max);
-  }
   // target side (:184)
   if (kGeneral) {
     integrate_attitude_rk45(e.qt, e.wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);
 #pragma unroll
     for (int i = 0; i < 3; ++i) e.wt[i] = canon(e.wt[i], tag);
   } else {
-#ifndef RDV_FAKE_NOTARGET   // timing experiment only (wrong results): the target side as if another wave had computed it
     integrate_attitude<kRaw>(e.qt, e.wt, P.half_dt);
-#endif
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) e.qt[i] = canon(e.qt[i], tag);

@@ -309,9 +309,9 @@ __device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i,
 
 // step one lane's env (or report a halted one); returns whether a transition was executed.  The observation goes to `sink(j, v)`
 // element by element (zeros for a lane without an env): see observation_to.
-template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false, typename Sink, typename Early = NoEarly>
+template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false, typename Sink>
 __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, int64_t i, bool active, Env& e, const float* a,
-                                        StepResult& r, Sink&& sink, Early&& early = Early{}) {
+                                        StepResult& r, Sink&& sink) {
   r.done = 0; r.reason = 0; r.reward = 0.0f; r.reward64 = 0.0;
   bool stepped = false;
   if (!active) {
@@ -324,7 +324,7 @@ __device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, i
       r.done = 1;
       if (kDiag && A.diag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
     } else {
-      step_env<ST, !kDiag, kGeneral, kRaw>(P, e, a, r, d, sink, early);
+      step_env<ST, !kDiag, kGeneral, kRaw>(P, e, a, r, d, sink);
       stepped = true;
       if (kDiag) {   // evaluator build only: keeps the training kernel short
         double dg[RDV_DIAG_DIM];
@@ -543,8 +543,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
 constexpr int kSplitEnvs = 256;      // envs per workgroup
 constexpr int kSplitBlock = 512;     // 8 waves
 
-// Round 3 measured the two obvious ways of shortening what stands in front of the barrier (both bit-identical, both SLOWER; code in
-// commits 794a540 and 8ad2438, evidence under profiles/):
+// Round 3 measured three ways of shortening what stands in front of the barrier (all bit-identical, all SLOWER; code in commits
+// 794a540, 8ad2438 and 93382df, evidence under profiles/):
 //  - the speculative reset split over TWO service waves per step wave (12-wave workgroup, chaser half | target half in LDS): the
 //    halves' chains are shorter (5,356 and 6,436 cycles to the barrier against 6,596) and the launch takes 7.01 us against 6.78
 //    (profiles/r03_split_service_waves_stamps.txt).  What bounds the time to the barrier is not either wave's chain but the SIMD's
@@ -555,7 +555,12 @@ constexpr int kSplitBlock = 512;     // 8 waves
 //    this workload's ends are attitude-error ends, known only after the chaser's attitude step — 83 % of the workgroups have one per
 //    step and pay a third barrier — and a dozen-lane by-part pass takes ~4,400 cycles beside the rest of the transition, not the
 //    ~1,200 its ~300 instructions suggest: its Philox blocks are quarter-rate integer multiplies on the same VALU the step wave is
-//    saturating (profiles/r03_split_hint_stamps.txt).
+//    saturating (profiles/r03_split_hint_stamps.txt);
+//  - no reset arithmetic on the chain at all (step_kernel_slots, commit 93382df): prepared slots in HBM, requested by the ending lanes
+//    ~40 % into the transition (branch-free), copied at the end, refilled by part beside the NEXT launch's step; no barrier: 7.49 us.
+//    The step waves' transition is no faster beside nearly idle service waves (it is a dependency chain through the chaser side, not
+//    an issue count: removing the whole target side from it gains 0.17 us), and the slot copy is work they did not have before
+//    (profiles/r03_split_slots_hint.txt).
 template <typename ST>
 __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
@@ -662,167 +667,6 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
   RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + wv)
 }
 
-
-// ---------------------------------------------------------------------------------------------------------------
-// Split roles WITHOUT the speculative reset (round 3, RDV_SPLIT_MODE=1): the next episode's state is the env's prepared slot in HBM
-// (rdv_slots.h).  No workgroup barrier at all:
-//   step waves    : the transition; ~40 % into it (step_env's `early` hook: the chaser side is known, and with it every end this
-//                   workload has) the lanes whose episode ends request their slot — 12 x 16 bytes — which travels while the target
-//                   side, the reward and the observation compute; at the end they copy it over their state and their observation row.
-//   service waves : refill, by part and for all 256 envs of the workgroup (wave r: part r), the slots of the envs that are at step 0
-//                   of an episode on entry — the ones whose slot was taken in the previous launch — beside the whole step.
-// Which slots are current is a function of the state alone: env i's slot holds reset(counter = episode_i) iff prep_tag[i] ==
-// episode_i + 1, and a launch only writes the slots (and tags) of envs with k == 0 on entry — which the step waves therefore never
-// trust: an env that ends its episode in its first step, or whose tag does not match, is reset in-lane (same expressions).
-template <typename ST>
-__global__ __launch_bounds__(kSplitBlock) void step_kernel_slots(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
-                                                       uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
-  StepArgs A = A_rest;
-  A.ws = ws_hot; A.actions = actions_hot; A.n = n_hot; A.stats = stats_hot; A.obs = obs_hot; A.reward = reward_hot;
-  using V = typename Vec4<ST>::type;
-  __shared__ __attribute__((aligned(16))) float stage[kSplitEnvs * RDV_OBS_DIM];   // observation rows
-  __shared__ uint16_t lists[kGroupWaves * kSplitEnvs];                              // per service wave: the envs to refill
-  __shared__ uint32_t counters[kGroupWaves * kSplitEnvs];                           // per service wave: their episode indices
-  static_assert(kSplitEnvs == kGroupEnvs, "one part per service wave over 256 envs");
-  const DevParams& P = *Pp;   // scalar loads: see step_kernel
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int64_t block_base = (int64_t)blockIdx.x * kSplitEnvs;
-  const int64_t n = A.n;
-  V* ws = reinterpret_cast<V*>(A.ws);
-  const bool resets = A.on_done == RDV_ON_DONE_RESET;
-  const SlotStore<ST> H = hbm_slot_store<ST>(A.prep);
-  RDV_STAMP_DECL
-  RDV_STAMP(0);
-
-  if (wv < kSplitEnvs / kWave) {
-    // ------------------------------------------------------------------ step waves
-    const int64_t wave_base = block_base + wv * kWave;
-    const int64_t i = wave_base + lane;
-    const bool active = i < n;
-    const int64_t rows = (n - wave_base) < kWave ? (n - wave_base) : kWave;
-    float* wl = stage + wv * (kWave * RDV_OBS_DIM);
-    Env e;
-    StepResult r;
-    if (active) load_env<ST>(ws, A.cs, i, e);
-    const uint32_t tag = (active && resets) ? A.prep_tag[i] : 0u;
-    uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-    const uint64_t slot_pre = stats_preload(slot, lane);
-    float a[RDV_ACT_DIM];
-    load_actions(A.actions, wave_base, lane, active, a);
-    RDV_STAMP(1);
-    bool slot_ok = false;
-    if (active && resets) slot_ok = e.k != 0 && tag == e.episode + 1u && !(A.xcd_per & 2);
-    // the slot's 12 vectors as native vector values (a struct copy of HIP's float4 is a memcpy, and one that is written on two paths
-    // stays an alloca: promoted to LDS, whose per-lane address needs the workgroup size from the dispatch packet — a scalar load from
-    // the queue in host memory at the head of every wave: 19 us per launch, measured)
-    using N4 = ST __attribute__((ext_vector_type(4)));
-    using F4 = float __attribute__((ext_vector_type(4)));
-    // (every loaded register stays live to the end: a destination with dead lanes — the padding of the fifth observation vector — is
-    //  reused by the allocator, and the write-after-write hazard then puts an s_waitcnt vmcnt(0) right behind the loads: +2,100 cycles)
-    N4 rc[kChunks];
-    F4 ro[kSlotObsVecs - 1];
-    float ro16;
-    auto fetch = [&](int64_t src) {
-#pragma unroll
-      for (int c = 0; c < kChunks; ++c) rc[c] = *reinterpret_cast<const N4*>(H.chunk(c, src));
-#pragma unroll
-      for (int v = 0; v < kSlotObsVecs - 1; ++v) ro[v] = *reinterpret_cast<const F4*>(H.ovec(v, src));
-      ro16 = *H.oelem(16, src);
-    };
-    bool fetched = false;
-    float obs_r[RDV_OBS_DIM];
-    float* my_row = wl + lane * RDV_OBS_DIM;
-#ifdef RDV_SLOTS_NOHOOK
-    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; });
-#else
-    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; },
-                                            // no branch inside the transition (it would split the one block the scheduler interleaves the chaser's and the target's
-                                            // chains in: 4,500 -> 6,500 cycles, stamps): every lane loads, the lanes that go on all read the wave's first record
-                                            [&](bool ends) { fetched = ends && slot_ok; fetch((fetched && !(A.xcd_per & 4)) ? i : wave_base); });
-#endif
-    RDV_STAMP(2);
-    const bool fin = stepped && r.done;
-    const bool to_reset = fin && resets;
-    if (to_reset && slot_ok && !fetched) fetch(i);   // an end the hint does not cover (Box.contains)
-    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-    if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);
-    RDV_STAMP(3);
-    stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
-    store_step_outputs<true>(A, i, active, fin, r, e, obs_r);
-    RDV_STAMP(4);
-    if (to_reset) {
-      if (slot_ok) {
-        if (s2u(rc[5].z) == kFlagsPending) {   // an initial state near the target: its collided / success flags need the whole state
-          SlotRaw<ST> raw;
-#pragma unroll
-          for (int c = 0; c < kChunks; ++c) { raw.c[c].x = rc[c].x; raw.c[c].y = rc[c].y; raw.c[c].z = rc[c].z; raw.c[c].w = rc[c].w; }
-#pragma unroll
-          for (int v = 0; v < kSlotObsVecs - 1; ++v) raw.o[v] = make_float4(ro[v].x, ro[v].y, ro[v].z, ro[v].w);
-          raw.o[kSlotObsVecs - 1] = make_float4(ro16, 0.0f, 0.0f, 0.0f);
-          Env ne;
-          float o[RDV_OBS_DIM];
-          slot_unpack<ST>(P, raw, ne, o);
-          rc[5].z = u2s(ne.flags, ST(0));
-        }
-#pragma unroll
-        for (int c = 0; c < kChunks; ++c) *reinterpret_cast<N4*>(&ws[c * A.cs + i]) = rc[c];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) { my_row[4 * v] = ro[v].x; my_row[4 * v + 1] = ro[v].y; my_row[4 * v + 2] = ro[v].z; my_row[4 * v + 3] = ro[v].w; }
-        my_row[16] = ro16;
-      } else {
-        Env ne;
-        float o[RDV_OBS_DIM];
-        reset_whole<ST>(P, ne, o, A.seed, A.env_id_offset + (uint64_t)i, e.episode, tape_row_of(A.tape, A.tape_depth, n, i, e.episode));
-        store_env<ST>(ws, A.cs, i, ne, true);
-#pragma unroll
-        for (int j = 0; j < RDV_OBS_DIM; ++j) my_row[j] = o[j];
-      }
-    }
-    RDV_STAMP(5);
-    wave_lds_fence();
-    store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);
-#ifdef RDV_STAMPS
-    stamp_[6] = stamp_[5] + __popcll(__ballot(to_reset)) + 100 * __popcll(__ballot(to_reset && slot_ok && fetched)) + 10000 * __popcll(__ballot(fetched));   // "phase 5>6": ends + 100 x early-fetched ends + 10000 x fetches
-#endif
-  } else if (resets) {
-    // ------------------------------------------------------------------ service waves
-    const int role = wv - kSplitEnvs / kWave;
-    uint16_t* list = lists + role * kSplitEnvs;
-    uint32_t* cnt = counters + role * kSplitEnvs;
-    bool flag[kGroupWaves];
-#pragma unroll
-    for (int q = 0; q < kGroupWaves; ++q) {
-      const int64_t ii = block_base + q * kWave + lane;
-      flag[q] = false;
-      if (ii < n) {
-        const V c5 = ws[5 * A.cs + ii];
-        flag[q] = s2u(c5.y) == 0u && !(A.xcd_per & 1);          // step 0 of an episode: the slot was taken (or is unknown) — refilled for the episode after
-        cnt[q * kWave + lane] = s2u(c5.w);
-      }
-    }
-    RDV_STAMP(1);
-    const int total = compact_flags<kGroupWaves>(flag, lane, list);
-    RDV_STAMP(2);
-#pragma clang loop unroll(disable)
-    for (int j0 = 0; j0 < total; j0 += kWave) {
-      const int j = j0 + lane;
-      if (j < total) {
-        const int sidx = (int)list[j];
-        const uint32_t counter = cnt[sidx];
-        const int64_t ii = block_base + sidx;
-        slot_refill_role<ST>(role, P, H, ii, A.seed, A.env_id_offset + (uint64_t)ii, counter, tape_row_of(A.tape, A.tape_depth, n, ii, counter));
-        if (role == 0) A.prep_tag[ii] = counter + 1u;
-      }
-    }
-    RDV_STAMP(3);
-#ifdef RDV_STAMPS
-    stamp_[4] = stamp_[3] + total; stamp_[5] = stamp_[4]; stamp_[6] = stamp_[5];   // "phase 3>4" = entries refilled
-#endif
-  }
-  RDV_STAMP(7);
-  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * 8 + (threadIdx.x >> 6))
-}
 
 // reset() for all envs or where mask != 0; the env's prepared slot is refilled for the episode after the one that starts here
 template <typename ST>
@@ -1673,18 +1517,10 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   const bool split = !A.diag && !A.eval && !h->general && !raw && (h->variant == RDV_VARIANT_SPLIT || (h->variant == RDV_VARIANT_AUTO && h->n <= kSplitAutoMaxEnvs));
 #define RDV_LAUNCH(KERNEL, GRID, BLOCK) hipLaunchKernelGGL((KERNEL), GRID, BLOCK, 0, s, A.ws, A.actions, h->dev_params, A.n, A.stats, A.obs, A.reward, A)
   const bool f32 = h->storage == RDV_STORAGE_F32, dg = A.diag != nullptr || A.eval != nullptr;   // either one: the evaluator build
-  bool slots = false;
   if (split) {
     const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs));
     const dim3 block(kSplitBlock);
-    static const int split_mode = std::getenv("RDV_SPLIT_MODE") ? std::atoi(std::getenv("RDV_SPLIT_MODE")) : 0;
-    slots = split_mode == 1 && h->on_done == RDV_ON_DONE_RESET;
-    if (slots) {
-      const int rc = ensure_prepared(h, s);
-      if (rc != RDV_OK) return rc;
-      A.xcd_per = std::getenv("RDV_SLOTS_DEBUG") ? std::atoi(std::getenv("RDV_SLOTS_DEBUG")) : 0;
-      if (f32) RDV_LAUNCH(step_kernel_slots<float>, grid, block); else RDV_LAUNCH(step_kernel_slots<double>, grid, block);
-    } else if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
+    if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
   } else {
     dim3 grid = grid_for(h->n), block(kBlock);
     A.stream_rows = h->n <= kStreamRowsMaxEnvs ? 1 : 0;
@@ -1707,7 +1543,7 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   }
 #undef RDV_LAUNCH
   RDV_HIP(hipGetLastError());
-  if (h->on_done == RDV_ON_DONE_RESET && !slots) h->prepared_ok = false;   // the step kernels reset in registers: the slots of the persistent kernels lag behind now (step_kernel_slots keeps slots and tags consistent itself)
+  if (h->on_done == RDV_ON_DONE_RESET) h->prepared_ok = false;   // the step kernels reset in registers: the slots of the persistent kernels lag behind now
   return RDV_OK;
 }
 
