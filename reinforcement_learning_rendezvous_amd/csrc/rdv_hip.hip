@@ -472,6 +472,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
   float* wl = lds + wave_in_block * (kWave * RDV_OBS_DIM);
   V* ws = reinterpret_cast<V*>(A.ws);
   const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform: the barriers below are executed by all waves or by none
+  RDV_STAMP_DECL
+  RDV_STAMP(0);
 
   {
     V* wsw = ws + wave_base;                             // this wave's slice of every chunk array: chunk c of lane l at wsw[c * cs + l]
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
     StepResult r;
     const RowSink my_row{wl + lane * RDV_OBS_DIM};      // the observation is staged as it is formed
     const bool stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row);
+    RDV_STAMP(2);
     const bool fin = stepped && r.done;
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
     store_step_outputs<true>(Aw, lane, active, fin, r, e, my_row.row);
@@ -501,18 +504,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
     }
     if (stepped && !to_reset) store_env<ST>(wsw, A.cs, lane, e, false);   // a listed env's state is written by the parts, all seven chunks
   }
+  RDV_STAMP(3);
   if (resets) {
     __syncthreads();   // the workgroup's finished envs are listed, every observation row is staged
+    RDV_STAMP(4);
     LiveStore<ST> L;
     L.ws = ws; L.rows = lds; L.cs = A.cs; L.base = block_base;
     refill_pass_lds<ST>(wave_in_block, lane, P, L, job_kind, job_counter, lists + wave_in_block * kBlock, block_base, n, A.seed,
                         A.env_id_offset, A.tape, A.tape_depth);
+    RDV_STAMP(5);
     __syncthreads();   // SB3 DummyVecEnv semantics: the rows of the listed envs now hold the first observation of the next episode
   } else {
     wave_lds_fence();
   }
+  RDV_STAMP(6);
   if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see kStreamRowsMaxEnvs
   else store_obs_rows<false>(A.obs, wave_base, rows, lane, wl);
+  RDV_STAMP(7);
+  RDV_STAMP_FLUSH((uint64_t)blockIdx.x * (kBlock / kWave) + wave_in_block)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
