@@ -30,7 +30,10 @@
 // the actor itself spills: 20.7 us per step; (b') dedicated service waves as in rdv_step_many.h, with four actor waves of two 32-env
 // tiles each to stay at three waves per SIMD — the env phase drops to 4.5 us but a lone actor wave per SIMD no longer overlaps its
 // MFMAs with another wave's vector work and the actor phase grows to 8.4 us: 12.9 us per step with float32 state, 11.8 (from 11.5)
-// with float64; (c) shifting the two actor waves of a SIMD against each other or prioritising one.)
+// with float64; (c) shifting the two actor waves of a SIMD against each other or prioritising one; (d) round 3: the workgroup as two
+// six-wave halves (two env waves + their four actor waves) with their own LDS barriers, job lists and by-part refills, taking their actor
+// phases in turn so that one half's env phase runs beside the other half's actor phase: 9.5-10.5 us per step against 7.9 — polled
+// barriers cost more than the overlap frees — and not reliably bit-identical (profiles/r03_rollout_two_halves.txt).)
 #pragma once
 
 namespace rdv {
