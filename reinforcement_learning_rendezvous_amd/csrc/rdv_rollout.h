@@ -33,7 +33,9 @@
 // with float64; (c) shifting the two actor waves of a SIMD against each other or prioritising one; (d) round 3: the workgroup as two
 // six-wave halves (two env waves + their four actor waves) with their own LDS barriers, job lists and by-part refills, taking their actor
 // phases in turn so that one half's env phase runs beside the other half's actor phase: 9.5-10.5 us per step against 7.9 — polled
-// barriers cost more than the overlap frees — and not reliably bit-identical (profiles/r03_rollout_two_halves.txt).)
+// barriers cost more than the overlap frees — and not reliably bit-identical (profiles/r03_rollout_two_halves.txt); (e) the halves as
+// separate 128-env workgroups of six waves (hardware barriers, 75 KB of LDS each), two per CU: 11.8 us per step — at three waves per
+// SIMD a second six-wave workgroup does not pack beside the first (2+2+1+1 waves over the four SIMDs).)
 #pragma once
 
 namespace rdv {
