@@ -6,7 +6,7 @@ behind the reference's Gym / SB3-VecEnv API.  See DESIGN.md and include/rdv.h.
 from .params import EnvParams, make_params, params_from_config  # noqa: F401
 from ._native import RdvError, build  # noqa: F401
 
-__all__ = ["EnvParams", "make_params", "params_from_config", "RdvError", "build", "RendezvousBatch"]
+__all__ = ["EnvParams", "make_params", "params_from_config", "RdvError", "build", "RendezvousBatch", "RendezvousVecEnv", "RendezvousEnv", "MlpPolicy"]
 
 
 def __getattr__(name):   # torch is imported only when the device classes are used
@@ -16,6 +16,9 @@ def __getattr__(name):   # torch is imported only when the device classes are us
     if name == "RendezvousVecEnv":
         from .vec_env import RendezvousVecEnv
         return RendezvousVecEnv
+    if name == "RendezvousEnv":
+        from .gym_env import RendezvousEnv
+        return RendezvousEnv
     if name == "MlpPolicy":
         from .policy import MlpPolicy
         return MlpPolicy

@@ -1,0 +1,140 @@
+"""RendezvousEnv — the reference's Gym 0.21 ``Env`` surface (rendezvous_env.py:10-291) for ONE env on the HIP engine.
+
+SURVEY §8(b)(i): the object the reference's own scripts hold (``env = RendezvousEnv(**kwargs)``; monte_carlo.py:96-135,
+save_new_trajectory.py:139-170, custom_callbacks.py:199-253, verification/*.py): same constructor keywords, ``reset() -> obs``,
+``step(action) -> (obs, rew, done, info)`` with the reference's ``info`` keys (:214-219), the state / bookkeeping attributes those
+scripts read and WRITE between steps (``env.rc = ...`` after ``reset()``, monte_carlo.py:107-112) and the helper methods they call
+(``get_errors``, ``check_collision``, ``check_success``, ``dist_from_koz``, ``get_observation``, ...).  Gym semantics: no auto-reset —
+``done`` is reported and the caller resets (or, like the verification scripts, keeps stepping).
+
+It is a batch of one env on the same kernels as everything else (``RendezvousBatch(1, on_done="continue")``): every call is a kernel
+launch plus a small device -> host copy, ~10^4 steps/s — two orders of magnitude above the reference's 260-390 steps/s, five below
+the batched path.  Use ``RendezvousVecEnv`` / ``RendezvousBatch`` for throughput; use this to run the reference's single-env scripts
+unchanged.
+"""
+import numpy as np
+import torch
+
+from .params import FIELD_NAMES, make_params
+from .vec_env import _AUX_ATTRS, _DIAG_METHODS, _STATE_ATTRS, _box
+
+
+class RendezvousEnv:
+    metadata = {"render.modes": []}
+
+    def __init__(self, *args, device="cuda:0", storage="f64", seed=0, engine=None, **kwargs):
+        """``kwargs`` (and positional ``args``, in the reference's order): the reference constructor's arguments
+        (rendezvous_env.py:17-37).  ``storage``: "f64" by default — the reference's own precision, which a single env can afford.
+        ``engine``: an already constructed one-env batch (tests inject the CPU-oracle-backed twin)."""
+        names = ["rc0", "vc0", "qc0", "wc0", "qt0", "wt0", "rc0_range", "vc0_range", "qc0_range", "wc0_range", "qt0_range",
+                 "wt0_range", "koz_radius", "corridor_half_angle", "h", "dt", "t_max", "reward_kwargs", "quiet"]   # :17-37
+        if len(args) > len(names):
+            raise TypeError(f"RendezvousEnv takes at most {len(names)} positional arguments")
+        for k, v in zip(names, args):
+            if k in kwargs:
+                raise TypeError(f"RendezvousEnv got multiple values for argument '{k}'")
+            kwargs[k] = v
+        self.quiet = bool(kwargs.pop("quiet", False))
+        if engine is None:
+            from .batch import RendezvousBatch
+            engine = RendezvousBatch(1, params=make_params(**kwargs), device=device, storage=storage, on_done="continue", seed=seed)
+        if engine.num_envs != 1:
+            raise ValueError("RendezvousEnv wraps a batch of exactly one env")
+        object.__setattr__(self, "batch", engine)
+        self.observation_space = _box(-1, 1, (17,))        # :133-137
+        self.action_space = _box(-1, 1, (6,))              # :140-144
+        self.viewer = None                                 # :129
+        self._act = torch.zeros((1, 6), dtype=torch.float32, device=engine.device)
+
+    # ------------------------------------------------------------------------------------------------ Gym API
+    def reset(self):
+        return self.batch.reset().cpu().numpy()[0].copy()                       # :223-270
+
+    def step(self, action):
+        a = np.asarray(action, dtype=np.float32)
+        assert a.shape == (6,), f"expected an action of shape (6,), got {a.shape}"   # :168
+        self._act.copy_(torch.from_numpy(a.reshape(1, 6)))
+        obs, rew, done = self.batch.step(self._act)
+        obs = obs.cpu().numpy()[0].copy()
+        rew = float(rew.cpu().numpy()[0])
+        done = bool(done.cpu().numpy()[0])
+        if done and not self.quiet:                                             # :376-382
+            s = self.batch.get_state().cpu().numpy()[0]
+            reason = int(self.batch.done_reason.cpu().numpy()[0])
+            t_end = self.t
+            t_end = int(t_end) if float(self.batch.params.dt).is_integer() else t_end
+            print("Episode end | r = " + str(round(float(np.linalg.norm(s[0:3])), 2)).rjust(5) + " | t = " + str(t_end).rjust(4) +
+                  " | " + ["", "obs", "time", "bubble", "attitude"][reason & 7].center(8) + " | " + ("Collided" if self.collided else " "))
+        info = {"observation": obs, "reward": rew, "done": done, "action": action}   # :214-219
+        return obs, rew, done, info
+
+    def render(self, mode="human"):      # :272-279 (the reference's viewer is a no-op stub)
+        return None
+
+    def close(self):                     # :281-291
+        self.viewer = None
+
+    def seed(self, seed=None):
+        self.batch.seed(0 if seed is None else int(seed))
+        return [seed]
+
+    # ------------------------------------------------------------------------------------------------ attributes
+    def __getattr__(self, name):         # only reached for names that are not ordinary attributes
+        b = object.__getattribute__(self, "batch")
+        if name in _STATE_ATTRS:
+            return b.get_state().cpu().numpy()[0, _STATE_ATTRS[name]].copy()
+        if name in _AUX_ATTRS:
+            v = b.get_aux().cpu().numpy()[0, _AUX_ATTRS[name]]
+            return bool(v) if name == "collided" else (int(v) if name == "success" else float(v))
+        if name in FIELD_NAMES:
+            v = b.params.to_dict()[name]
+            return np.array(v) if isinstance(v, list) else v
+        if name == "reward_kwargs":
+            p = b.params
+            return dict(collision_coef=p.collision_coef, bonus_coef=p.bonus_coef, fuel_coef=p.fuel_coef, att_coef=p.att_coef)
+        if name in ("inertia", "inv_inertia", "inertia_target", "inv_inertia_target"):   # :75-80, :96-101
+            m = b.get_rigid_body()["inertia_target" if name.endswith("target") else "inertia"]
+            return np.linalg.inv(m) if name.startswith("inv_") else m.copy()
+        raise AttributeError(f"'RendezvousEnv' object has no attribute '{name}'")
+
+    def __setattr__(self, name, value):
+        if name in _STATE_ATTRS:         # env.rc = ... (monte_carlo.py:107-112): the other fields keep their values
+            s = self.batch.get_state().cpu()
+            s[0, _STATE_ATTRS[name]] = torch.as_tensor(np.asarray(value, dtype=np.float64))
+            self.batch.set_state(s)
+        elif name == "reward_kwargs":
+            self.batch.set_reward_kwargs(**value)
+        elif name in FIELD_NAMES:
+            p = self.batch.params.copy()
+            p.update(**{name: value})
+            self.batch.set_params(p)
+        elif name in ("inertia", "inertia_target"):
+            self.batch.set_rigid_body(**{name: value})
+        elif name in _AUX_ATTRS:
+            raise AttributeError(f"'{name}' is bookkeeping the step writes (rendezvous_env.py:187-202); it cannot be set from outside")
+        else:
+            object.__setattr__(self, name, value)
+
+    # ------------------------------------------------------------------------------------------------ helper methods
+    def _diag(self, method):
+        d = self.batch.diagnose().cpu().numpy()[0]
+        sel = _DIAG_METHODS[method]
+        return d[sel].copy() if isinstance(sel, slice) else d[sel]
+
+    def get_observation(self):
+        return self.batch.observe().cpu().numpy()[0].copy()                     # :294-311
+
+    def get_errors(self):
+        return self._diag("get_errors")                                         # :451-468 [pos, vel, att, rate]
+
+    def get_attitude_error(self):
+        return float(self._diag("get_attitude_error"))                          # :424-434
+
+    def check_collision(self):
+        return bool(self._diag("check_collision"))                              # :388-404
+
+    def check_success(self):
+        return int(self._diag("check_success"))                                 # :406-422
+
+    def dist_from_koz(self):
+        return float(self._diag("dist_from_koz"))                               # :510-537

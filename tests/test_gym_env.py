@@ -1,0 +1,98 @@
+"""
+The single-env Gym surface (rendezvous_env.py:10-291) — ``RendezvousEnv`` — replaying the reference's recorded
+transitions (tests/golden/steps_A_random.npz: the unmodified reference env, random actions, its own resets) THROUGH THE GYM API, the way
+the reference's scripts drive the env object: ``reset()``, state written through the attributes (monte_carlo.py:107-112), ``step(a)``,
+attributes and helper methods read back after every step.  On the CPU with the oracle injected as the engine (host logic), on the
+GPU with the HIP engine (fp64 storage).
+"""
+import numpy as np
+import pytest
+
+from helpers import load_golden, params_from_note
+from reinforcement_learning_rendezvous_amd.gym_env import RendezvousEnv
+from reinforcement_learning_rendezvous_amd.vec_env import _STATE_ATTRS
+
+
+def _set_state(env, s):
+    for name, sl in _STATE_ATTRS.items():       # env.rc = ..., env.vc = ..., ... as monte_carlo.py:107-112
+        setattr(env, name, s[sl])
+
+
+def _replay(env, g, i, tol_state):
+    T = g["actions"].shape[0]
+    obs = env.reset()
+    assert obs.shape == (17,) and obs.dtype == np.float32 and env.observation_space.contains(obs)
+    assert env.t == 0 and env.total_delta_v == 0 and env.total_delta_w == 0 and env.collided is False and env.success == 0   # :261-266
+    np.testing.assert_array_equal(g["tape"][0, i], g["state0"][i])
+    _set_state(env, g["state0"][i])
+    np.testing.assert_array_equal(env.get_observation(), g["obs0"][i])
+    np.testing.assert_allclose(np.concatenate([env.rc, env.vc, env.qc, env.wc, env.qt, env.wt]), g["state0"][i], rtol=0, atol=0)
+    n_done = 0
+    for t in range(T):
+        if not g["valid"][t, i]:
+            break
+        a = g["actions"][t, i]
+        obs, rew, done, info = env.step(a)
+        assert set(info) == {"observation", "reward", "done", "action"} and info["action"] is a and info["done"] is done   # :214-219
+        assert isinstance(rew, float) and isinstance(done, bool) and obs.dtype == np.float32
+        np.testing.assert_allclose(obs, g["obs_step"][t, i], rtol=0, atol=6e-8, err_msg=f"obs, step {t}")
+        assert abs(rew - g["reward"][t, i]) <= 1e-6, f"reward, step {t}"       # the step's reward output is float32
+        assert done == bool(g["done"][t, i]), f"done, step {t}"
+        if done:          # Gym semantics: the caller resets; the reference's next initial state is the recorded one (the reset tape)
+            n_done += 1
+            env.reset()
+            _set_state(env, g["tape"][n_done, i])
+            assert env.t == 0
+            continue
+        state = np.concatenate([env.rc, env.vc, env.qc, env.wc, env.qt, env.wt])
+        np.testing.assert_allclose(state, g["state"][t, i], rtol=0, atol=tol_state, err_msg=f"state, step {t}")
+        aux = np.array([env.t, env.bubble_radius, env.collided, env.success, env.total_delta_v, env.total_delta_w], dtype=np.float64)
+        np.testing.assert_allclose(aux, g["aux"][t, i], rtol=0, atol=1e-6, err_msg=f"bookkeeping, step {t}")
+        d = g["diag"][t, i]
+        np.testing.assert_allclose(env.get_errors(), d[0:4], rtol=0, atol=10 * tol_state)
+        assert abs(env.get_attitude_error() - d[2]) <= 10 * tol_state
+        assert env.check_collision() == bool(d[4]) and env.check_success() == int(d[5])
+        assert abs(env.dist_from_koz() - d[6]) <= 10 * tol_state
+    assert n_done == int(g["done"][:, i][g["valid"][:, i].astype(bool)].sum()) and n_done >= 1
+
+
+def test_gym_env_replays_the_reference_through_its_own_api_on_the_oracle():
+    from oracle_engine import OracleEngine
+    g = load_golden("steps_A_random.npz")
+    p, _ = params_from_note(g["env_kwargs_json"])
+    for i in (0, 7):
+        env = RendezvousEnv(engine=OracleEngine(1, p, storage="f64", on_done="continue", seed=3), quiet=True)
+        _replay(env, g, i, tol_state=1e-11)
+
+
+def test_gym_env_constructor_and_attribute_surface():
+    from oracle_engine import OracleEngine
+    from reinforcement_learning_rendezvous_amd.params import make_params
+    p = make_params(t_max=30.0, koz_radius=4.0)
+    env = RendezvousEnv(engine=OracleEngine(1, p, storage="f64", on_done="continue", seed=1), quiet=True)
+    assert env.t_max == 30.0 and env.koz_radius == 4.0 and env.dt == 1.0 and env.rd.shape == (3,)       # constructor values, by name
+    assert env.observation_space.shape == (17,) and env.action_space.shape == (6,)
+    env.reset()
+    with pytest.raises(AttributeError):
+        env.t = 3.0                            # bookkeeping is the step's (rendezvous_env.py:187-202)
+    with pytest.raises(AttributeError):
+        env.no_such_attribute
+    with pytest.raises(AssertionError):
+        env.step(np.zeros(5, np.float32))      # :168
+    env.rc = np.array([0.0, -3.0, 0.0])        # inside the keep-out sphere, on the corridor axis
+    assert np.array_equal(env.rc, [0.0, -3.0, 0.0]) and env.vc.shape == (3,) and env.qc.shape == (4,)
+    assert env.render() is None and env.close() is None
+
+
+@pytest.mark.gpu
+def test_gym_env_replays_the_reference_through_its_own_api_on_the_gpu():
+    g = load_golden("steps_A_random.npz")
+    import json
+    kw = json.loads(str(g["env_kwargs_json"]))
+    for k in ("rc0", "vc0", "qc0", "wc0", "qt0", "wt0"):
+        if k in kw:
+            kw[k] = np.array(kw[k], dtype=np.float64)
+    for i in (0, 7):
+        env = RendezvousEnv(device="cuda:0", storage="f64", seed=3, quiet=True, **kw)
+        _replay(env, g, i, tol_state=1e-10)
+        env.close()
