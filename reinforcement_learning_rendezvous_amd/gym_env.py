@@ -4,7 +4,8 @@ SURVEY §8(b)(i): the object the reference's own scripts hold (``env = Rendezvou
 save_new_trajectory.py:139-170, custom_callbacks.py:199-253, verification/*.py): same constructor keywords, ``reset() -> obs``,
 ``step(action) -> (obs, rew, done, info)`` with the reference's ``info`` keys (:214-219), the state / bookkeeping attributes those
 scripts read and WRITE between steps (``env.rc = ...`` after ``reset()``, monte_carlo.py:107-112) and the helper methods they call
-(``get_errors``, ``check_collision``, ``check_success``, ``dist_from_koz``, ``get_observation``, ...).  Gym semantics: no auto-reset —
+(``get_errors``, ``check_collision``, ``check_success``, ``dist_from_koz``, ``get_observation``, the frame transforms
+``chaser2lvlh`` / ``target2lvlh`` / ..., ``get_goal_pos``, ``get_pos_error``).  Gym semantics: no auto-reset —
 ``done`` is reported and the caller resets (or, like the verification scripts, keeps stepping).
 
 It is a batch of one env on the same kernels as everything else (``RendezvousBatch(1, on_done="continue")``): every call is a kernel
@@ -138,3 +139,37 @@ class RendezvousEnv:
 
     def dist_from_koz(self):
         return float(self._diag("dist_from_koz"))                               # :510-537
+
+    # Frame transforms of a caller's vector by the current attitude (:436-508; what the verification/ scripts plot).  Host-side: they
+    # are not part of a transition — the step kernels form the same rotation matrices for their own use.
+    @staticmethod
+    def _rotation(q):
+        q = np.asarray(q, dtype=np.float64)
+        qw, qx, qy, qz = q / np.sqrt(np.sum(q * q))                             # utils/quaternions.py:57-66 (scalar first)
+        return np.array([[2 * (qw ** 2 + qx ** 2) - 1, 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
+                         [2 * (qx * qy + qw * qz), 2 * (qw ** 2 + qy ** 2) - 1, 2 * (qy * qz - qw * qx)],
+                         [2 * (qx * qz - qw * qy), 2 * (qy * qz + qw * qx), 2 * (qw ** 2 + qz ** 2) - 1]])
+
+    @staticmethod
+    def _vec3(vec):
+        v = np.asarray(vec, dtype=np.float64)
+        assert v.shape == (3,), f"Vector must have a (3,) shape, but has {v.shape}"   # :478 etc.
+        return v
+
+    def lvlh2chaser(self, vec):
+        return self._rotation(self.qc).T @ self._vec3(vec)                      # :470-478
+
+    def lvlh2target(self, vec):
+        return self._rotation(self.qt).T @ self._vec3(vec)                      # :480-488
+
+    def chaser2lvlh(self, vec):
+        return self._rotation(self.qc) @ self._vec3(vec)                        # :490-498
+
+    def target2lvlh(self, vec):
+        return self._rotation(self.qt) @ self._vec3(vec)                        # :500-508
+
+    def get_goal_pos(self):
+        return self.target2lvlh(self.rd)                                        # :436-441
+
+    def get_pos_error(self, goal_position):
+        return float(np.linalg.norm(self.rc - np.asarray(goal_position, dtype=np.float64)))   # :443-449

@@ -53,6 +53,12 @@ def _replay(env, g, i, tol_state):
         assert abs(env.get_attitude_error() - d[2]) <= 10 * tol_state
         assert env.check_collision() == bool(d[4]) and env.check_success() == int(d[5])
         assert abs(env.dist_from_koz() - d[6]) <= 10 * tol_state
+        if t % 16 == 0:   # the script-side helpers agree with the kernel's diagnostics: position error (:443-449 with :436-441)
+            assert abs(env.get_pos_error(env.get_goal_pos()) - d[0]) <= 1e-9
+            v = np.array([0.3, -1.2, 2.0])
+            np.testing.assert_allclose(env.lvlh2chaser(env.chaser2lvlh(v)), v, rtol=0, atol=1e-14)
+            np.testing.assert_allclose(env.lvlh2target(env.target2lvlh(v)), v, rtol=0, atol=1e-14)
+            assert abs(np.linalg.norm(env.chaser2lvlh(v)) - np.linalg.norm(v)) <= 1e-14
     assert n_done == int(g["done"][:, i][g["valid"][:, i].astype(bool)].sum()) and n_done >= 1
 
 
