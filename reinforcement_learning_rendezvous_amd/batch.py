@@ -38,6 +38,8 @@ class RendezvousBatch:
         self.env_id_offset = int(env_id_offset)       # global index of local env 0 (sharded batches)
         self.storage = _STORAGE[storage]
         self.on_done = _ON_DONE[on_done]
+        self._ctor = dict(storage=storage, on_done=on_done, variant=variant)   # for clone()
+        self._seed, self._fresh = int(seed), True
         self._lib = N.lib()
         self._h = C.c_void_p()
         dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -147,6 +149,7 @@ class RendezvousBatch:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             self._check_tensor(mask, (self.num_envs,), torch.uint8, "mask")
             mptr = mask.data_ptr()
+        self._fresh = False
         if mask is None:
             N.check(self._lib.rdv_reset(self._h, None, self.obs.data_ptr(), self._stream()))
         else:
@@ -284,7 +287,29 @@ class RendezvousBatch:
             raise ValueError("restore: not a snapshot of a batch of this size / storage on this device")
         snap = snap.contiguous()
         N.check(self._lib.rdv_restore(self._h, snap.data_ptr(), snap.numel(), self._stream()))
+        self._fresh = False
         self.obs.copy_(self.observe())
+
+    def clone(self):
+        """An independent batch in the same state — what ``copy.deepcopy(env)`` gives the reference (utils/environment_utils.py:66-73;
+        main.py:83 makes its ``eval_env`` that way): same parameters, rigid bodies, seed, reset tape and kernel variant; state,
+        bookkeeping, episode counters and statistics through ``snapshot`` / ``restore``.  The two share nothing afterwards."""
+        other = RendezvousBatch(self.num_envs, params=self.params, device=self.device, seed=self._seed,
+                                env_id_offset=self.env_id_offset, **self._ctor)
+        body = self.get_rigid_body()
+        other.set_rigid_body(inertia=body["inertia"], inertia_target=body["inertia_target"], torque=body["torque"],
+                             torque_target=body["torque_target"], integrator=body["integrator"], rtol=body["rtol"], atol=body["atol"])
+        if self._tape is not None:
+            other.set_reset_tape(self._tape.clone())
+        if not self._fresh:
+            other.restore(self.snapshot())
+            other.reward.copy_(self.reward); other.done.copy_(self.done)
+            for name in ("terminal_obs", "episode_return", "episode_length", "done_reason"):
+                getattr(other, name).copy_(getattr(self, name))
+        return other
+
+    def __deepcopy__(self, memo):
+        return self.clone()
 
     def get_stats(self, reset=False):
         st = N.Stats()
@@ -294,6 +319,7 @@ class RendezvousBatch:
     # ------------------------------------------------------------------------------------------------ configuration
     def seed(self, seed):
         N.check(self._lib.rdv_seed(self._h, C.c_uint64(seed)))
+        self._seed = int(seed)
 
     def set_reset_tape(self, tape):
         """tape: [depth, N, 20] float64 initial states replacing the RNG resets (parity tests); None to clear."""

@@ -79,6 +79,10 @@ class RendezvousEnv:
         self.batch.seed(0 if seed is None else int(seed))
         return [seed]
 
+    def __deepcopy__(self, memo):        # copy_env(env) (utils/environment_utils.py:66-73; main.py:83)
+        import copy
+        return RendezvousEnv(engine=copy.deepcopy(self.batch, memo), quiet=self.quiet)
+
     # ------------------------------------------------------------------------------------------------ attributes
     def __getattr__(self, name):         # only reached for names that are not ordinary attributes
         b = object.__getattribute__(self, "batch")

@@ -105,6 +105,11 @@ class RendezvousVecEnv(_VecEnvBase):
             gc.collect()
             gc.freeze()
 
+    def __deepcopy__(self, memo):        # copy_env(train_env) -> eval_env (utils/environment_utils.py:66-73; main.py:83)
+        import copy
+        return RendezvousVecEnv(self.num_envs, engine=copy.deepcopy(self.batch, memo), quiet=self.quiet,
+                                copy_outputs=self.copy_outputs, gc_freeze=False)
+
     # ------------------------------------------------------------------------------------------------ VecEnv API
     def reset(self):
         return self.batch.reset().cpu().numpy()

@@ -102,3 +102,47 @@ def test_gym_env_replays_the_reference_through_its_own_api_on_the_gpu():
         env = RendezvousEnv(device="cuda:0", storage="f64", seed=3, quiet=True, **kw)
         _replay(env, g, i, tol_state=1e-10)
         env.close()
+
+
+@pytest.mark.gpu
+def test_deepcopy_gives_an_independent_env_in_the_same_state():
+    """copy_env(train_env) (utils/environment_utils.py:66-73; main.py:83 makes its eval_env this way): the copy continues exactly as
+    the original would (same resets: seed, env ids and episode counters travel), and the two share nothing."""
+    import copy
+    import torch
+    from helpers import counter_actions
+    from reinforcement_learning_rendezvous_amd.vec_env import RendezvousVecEnv
+    n = 300
+    a = RendezvousVecEnv(n, device="cuda:0", seed=5, quiet=True, t_max=12.0, gc_freeze=False)      # short episodes: resets within the test
+    a.reset()
+    for t in range(10):
+        a.step(counter_actions(2, t, n))
+    b = copy.deepcopy(a)
+    assert b is not a and b.batch is not a.batch and b.batch._ws.data_ptr() != a.batch._ws.data_ptr()
+    assert torch.equal(a.batch.get_state(), b.batch.get_state()) and torch.equal(a.batch.get_aux(), b.batch.get_aux())
+    n_done = 0
+    for t in range(10, 40):
+        oa, ra, da, ia = a.step(counter_actions(2, t, n))
+        oa, ra, da = oa.copy(), ra.copy(), da.copy()
+        ob, rb, db, ib = b.step(counter_actions(2, t, n))
+        np.testing.assert_array_equal(oa, ob); np.testing.assert_array_equal(ra, rb); np.testing.assert_array_equal(da, db)
+        for i in np.flatnonzero(da):
+            np.testing.assert_array_equal(ia[i]["terminal_observation"], ib[i]["terminal_observation"])
+            assert ia[i]["episode"]["r"] == ib[i]["episode"]["r"] and ia[i]["episode"]["l"] == ib[i]["episode"]["l"]
+        n_done += int(da.sum())
+    assert n_done > n                                             # every env was reset at least once on both sides, identically
+    before = a.batch.get_state().clone()
+    for t in range(5):
+        b.step(counter_actions(9, t, n))                          # the copy goes its own way ...
+    assert torch.equal(a.batch.get_state(), before)               # ... and the original has not moved
+    assert not torch.equal(b.batch.get_state(), before)
+    assert a.batch.get_stats()["env_steps"] == 40 * n and b.batch.get_stats()["env_steps"] == 45 * n
+
+    e = RendezvousEnv(device="cuda:0", storage="f64", seed=2, quiet=True)
+    e.reset()
+    e.step(np.full(6, 0.25, np.float32))
+    f = copy.deepcopy(e)
+    assert np.array_equal(e.rc, f.rc) and e.t == f.t == 1.0
+    o1, r1, d1, _ = e.step(np.full(6, -0.5, np.float32))
+    o2, r2, d2, _ = f.step(np.full(6, -0.5, np.float32))
+    assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2 and f.t == 2.0
