@@ -100,7 +100,24 @@ class RendezvousEnv:
         if name in ("inertia", "inv_inertia", "inertia_target", "inv_inertia_target"):   # :75-80, :96-101
             m = b.get_rigid_body()["inertia_target" if name.endswith("target") else "inertia"]
             return np.linalg.inv(m) if name.startswith("inv_") else m.copy()
+        if name in ("m", "max_wt", "mu", "Re"):                                          # the constructor's constants (:74, :88, :122-123)
+            from .evaluation import env_attributes
+            return env_attributes(b.params)[name]
         raise AttributeError(f"'RendezvousEnv' object has no attribute '{name}'")
+
+    def attributes(self):
+        """``vars(env)`` of the reference object (print_env, utils/environment_utils.py:76-88; the header of a trajectory record,
+        save_new_trajectory.py:172-204): parameters and constants under the reference's attribute names, the bodies actually integrated
+        with, and the current state and bookkeeping."""
+        from .evaluation import env_attributes
+        b = self.batch
+        out = env_attributes(b.params, b.get_rigid_body() if hasattr(b, "get_rigid_body") else None)
+        s, a = b.get_state().cpu().numpy()[0], b.get_aux().cpu().numpy()[0]
+        out.update({k: s[sl].copy() for k, sl in _STATE_ATTRS.items()})
+        out.update(t=float(a[0]), bubble_radius=float(a[1]), collided=bool(a[2]), success=int(a[3]), total_delta_v=float(a[4]),
+                   total_delta_w=float(a[5]), quiet=self.quiet, viewer=None, observation_space=self.observation_space,
+                   action_space=self.action_space)
+        return out
 
     def __setattr__(self, name, value):
         if name in _STATE_ATTRS:         # env.rc = ... (monte_carlo.py:107-112): the other fields keep their values

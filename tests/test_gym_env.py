@@ -88,6 +88,13 @@ def test_gym_env_constructor_and_attribute_surface():
     env.rc = np.array([0.0, -3.0, 0.0])        # inside the keep-out sphere, on the corridor axis
     assert np.array_equal(env.rc, [0.0, -3.0, 0.0]) and env.vc.shape == (3,) and env.qc.shape == (4,)
     assert env.render() is None and env.close() is None
+    v = env.attributes()                        # vars(env) of the reference object
+    for key in ("rc", "vc", "qc", "wc", "qt", "wt", "t", "collided", "success", "bubble_radius", "total_delta_v", "total_delta_w",
+                "nominal_rc0", "rc0_range", "dt", "t_max", "m", "inertia", "inv_inertia", "max_delta_v", "max_delta_w", "koz_radius",
+                "corridor_half_angle", "corridor_axis", "rd", "max_rd_error", "bubble_radius0", "bubble_min", "reward_kwargs", "mu",
+                "Re", "n", "quiet", "observation_space", "action_space"):
+        assert key in v, key
+    assert v["t_max"] == 30.0 and np.array_equal(v["rc"], [0.0, -3.0, 0.0]) and env.m == 100.0 and env.mu == 3.986004418e14
 
 
 @pytest.mark.gpu
