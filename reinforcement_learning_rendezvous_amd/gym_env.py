@@ -46,21 +46,31 @@ class RendezvousEnv:
         self.action_space = _box(-1, 1, (6,))              # :140-144
         self.viewer = None                                 # :129
         self._act = torch.zeros((1, 6), dtype=torch.float32, device=engine.device)
+        self._cache = None      # (state [20], aux [6]) of the current step, fetched on the first attribute read: a script that reads
+                                # rc, vc, qc, wc, t, collided ... after every step pays one pair of device -> host copies, not ten
 
     # ------------------------------------------------------------------------------------------------ Gym API
     def reset(self):
+        self._cache = None
         return self.batch.reset().cpu().numpy()[0].copy()                       # :223-270
+
+    def _now(self):
+        if self._cache is None:
+            b = self.batch
+            object.__setattr__(self, "_cache", (b.get_state().cpu().numpy()[0], b.get_aux().cpu().numpy()[0]))
+        return self._cache
 
     def step(self, action):
         a = np.asarray(action, dtype=np.float32)
         assert a.shape == (6,), f"expected an action of shape (6,), got {a.shape}"   # :168
         self._act.copy_(torch.from_numpy(a.reshape(1, 6)))
+        self._cache = None
         obs, rew, done = self.batch.step(self._act)
         obs = obs.cpu().numpy()[0].copy()
         rew = float(rew.cpu().numpy()[0])
         done = bool(done.cpu().numpy()[0])
         if done and not self.quiet:                                             # :376-382
-            s = self.batch.get_state().cpu().numpy()[0]
+            s = self._now()[0]
             reason = int(self.batch.done_reason.cpu().numpy()[0])
             t_end = self.t
             t_end = int(t_end) if float(self.batch.params.dt).is_integer() else t_end
@@ -87,9 +97,9 @@ class RendezvousEnv:
     def __getattr__(self, name):         # only reached for names that are not ordinary attributes
         b = object.__getattribute__(self, "batch")
         if name in _STATE_ATTRS:
-            return b.get_state().cpu().numpy()[0, _STATE_ATTRS[name]].copy()
+            return self._now()[0][_STATE_ATTRS[name]].copy()
         if name in _AUX_ATTRS:
-            v = b.get_aux().cpu().numpy()[0, _AUX_ATTRS[name]]
+            v = self._now()[1][_AUX_ATTRS[name]]
             return bool(v) if name == "collided" else (int(v) if name == "success" else float(v))
         if name in FIELD_NAMES:
             v = b.params.to_dict()[name]
@@ -112,7 +122,7 @@ class RendezvousEnv:
         from .evaluation import env_attributes
         b = self.batch
         out = env_attributes(b.params, b.get_rigid_body() if hasattr(b, "get_rigid_body") else None)
-        s, a = b.get_state().cpu().numpy()[0], b.get_aux().cpu().numpy()[0]
+        s, a = self._now()
         out.update({k: s[sl].copy() for k, sl in _STATE_ATTRS.items()})
         out.update(t=float(a[0]), bubble_radius=float(a[1]), collided=bool(a[2]), success=int(a[3]), total_delta_v=float(a[4]),
                    total_delta_w=float(a[5]), quiet=self.quiet, viewer=None, observation_space=self.observation_space,
@@ -121,9 +131,10 @@ class RendezvousEnv:
 
     def __setattr__(self, name, value):
         if name in _STATE_ATTRS:         # env.rc = ... (monte_carlo.py:107-112): the other fields keep their values
-            s = self.batch.get_state().cpu()
+            s = torch.from_numpy(self._now()[0].copy()).reshape(1, -1)
             s[0, _STATE_ATTRS[name]] = torch.as_tensor(np.asarray(value, dtype=np.float64))
             self.batch.set_state(s)
+            object.__setattr__(self, "_cache", None)
         elif name == "reward_kwargs":
             self.batch.set_reward_kwargs(**value)
         elif name in FIELD_NAMES:
