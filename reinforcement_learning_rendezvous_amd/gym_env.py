@@ -20,7 +20,14 @@ from .params import FIELD_NAMES, make_params
 from .vec_env import _AUX_ATTRS, _DIAG_METHODS, _STATE_ATTRS, _box
 
 
-class RendezvousEnv:
+try:                                   # the reference subclasses gym.Env (rendezvous_env.py:10); gym is optional here
+    import gym as _gym
+    _EnvBase = _gym.Env
+except Exception:                      # pragma: no cover - depends on the installation
+    _EnvBase = object
+
+
+class RendezvousEnv(_EnvBase):
     metadata = {"render.modes": []}
 
     def __init__(self, *args, device="cuda:0", storage="f64", seed=0, engine=None, **kwargs):
