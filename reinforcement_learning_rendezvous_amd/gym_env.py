@@ -120,6 +120,9 @@ class RendezvousEnv(_EnvBase):
         if name in ("m", "max_wt", "mu", "Re"):                                          # the constructor's constants (:74, :88, :122-123)
             from .evaluation import env_attributes
             return env_attributes(b.params)[name]
+        if name in ("ro", "h"):                                                          # :124-126, from the mean motion the batch holds
+            ro = (3.986004418e14 / float(b.params.n) ** 2) ** (1.0 / 3.0)
+            return ro if name == "ro" else ro - 6371e3
         raise AttributeError(f"'RendezvousEnv' object has no attribute '{name}'")
 
     def attributes(self):

@@ -94,6 +94,7 @@ def test_gym_env_constructor_and_attribute_surface():
                 "corridor_half_angle", "corridor_axis", "rd", "max_rd_error", "bubble_radius0", "bubble_min", "reward_kwargs", "mu",
                 "Re", "n", "quiet", "observation_space", "action_space"):
         assert key in v, key
+    assert abs(env.h - 800e3) < 1e-3 and abs(env.ro - (6371e3 + 800e3)) < 1e-3          # :123-125 defaults, recovered from n
     assert v["t_max"] == 30.0 and np.array_equal(v["rc"], [0.0, -3.0, 0.0]) and env.m == 100.0 and env.mu == 3.986004418e14
 
 
