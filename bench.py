@@ -539,6 +539,33 @@ def main():
         except Exception as exc:  # pragma: no cover - depends on the runtime
             out["open_loop_multi_step"] = {"error": repr(exc)}
 
+    # ---- informational: BASELINE config 1 — ONE env, 1000 steps, driven through the reference's own Gym object surface
+    #      (RendezvousEnv: reset() / step(a) -> obs, rew, done, info, reset on done), every step a launch + host round trips
+    if rank == 0 and world == 1:
+        try:
+            import numpy as np
+            from reinforcement_learning_rendezvous_amd.gym_env import RendezvousEnv
+            g1 = RendezvousEnv(device=str(device), storage="f64", seed=0, quiet=True)
+            acts1 = np.random.default_rng(1).uniform(-1, 1, (1000, 6)).astype(np.float32)
+            g1.reset()
+            for t in range(50):
+                if g1.step(acts1[t])[2]:
+                    g1.reset()
+            c0 = time.perf_counter()
+            episodes1 = 0
+            for t in range(1000):
+                if g1.step(acts1[t])[2]:
+                    g1.reset(); episodes1 += 1
+            c1 = time.perf_counter()
+            out["config1_single_env_gym_object"] = {"value": 1000 / (c1 - c0), "unit": "env steps/s", "steps": 1000, "episodes": episodes1,
+                                                    "storage": "f64",
+                                                    "note": "one env through RendezvousEnv (the reference's Gym API; state in fp64): a kernel launch, a 24-byte "
+                                                            "upload and three small downloads per step; the unmodified reference runs this config at 260-390 "
+                                                            "steps/s (cpu_baseline.reference_python)"}
+            g1.close(); del g1
+        except Exception as exc:  # pragma: no cover - depends on the runtime
+            out["config1_single_env_gym_object"] = {"error": repr(exc)}
+
     # ---- informational: MLP-policy rollout (config 3), N=1 only
     if rank == 0 and world == 1 and not args.no_policy:
         from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
