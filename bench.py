@@ -559,8 +559,8 @@ def main():
             c1 = time.perf_counter()
             out["config1_single_env_gym_object"] = {"value": 1000 / (c1 - c0), "unit": "env steps/s", "steps": 1000, "episodes": episodes1,
                                                     "storage": "f64",
-                                                    "note": "one env through RendezvousEnv (the reference's Gym API; state in fp64): a kernel launch, a 24-byte "
-                                                            "upload and three small downloads per step; the unmodified reference runs this config at 260-390 "
+                                                    "note": "one env through RendezvousEnv (the reference's Gym API; state in fp64): a 24-byte upload, a kernel "
+                                                            "launch and one small download per step; the unmodified reference runs this config at 260-390 "
                                                             "steps/s (cpu_baseline.reference_python)"}
             g1.close(); del g1
         except Exception as exc:  # pragma: no cover - depends on the runtime

@@ -9,7 +9,7 @@ scripts read and WRITE between steps (``env.rc = ...`` after ``reset()``, monte_
 ``done`` is reported and the caller resets (or, like the verification scripts, keeps stepping).
 
 It is a batch of one env on the same kernels as everything else (``RendezvousBatch(1, on_done="continue")``): every call is a kernel
-launch plus a small device -> host copy, ~10^4 steps/s — two orders of magnitude above the reference's 260-390 steps/s, five below
+launch plus a small device -> host copy, ~2.5 x 10^4 steps/s — two orders of magnitude above the reference's 260-390 steps/s, five below
 the batched path.  Use ``RendezvousVecEnv`` / ``RendezvousBatch`` for throughput; use this to run the reference's single-env scripts
 unchanged.
 """
@@ -53,6 +53,15 @@ class RendezvousEnv(_EnvBase):
         self.action_space = _box(-1, 1, (6,))              # :140-144
         self.viewer = None                                 # :129
         self._act = torch.zeros((1, 6), dtype=torch.float32, device=engine.device)
+        self._msg = None        # HIP engine: the step's obs | reward | done | done_reason as ONE device buffer the kernel writes in place
+        if hasattr(engine, "bind_outputs"):                # (one download per step instead of three)
+            from .sharding import PlanarMessage
+            m = PlanarMessage([("obs", (1, 17), torch.float32), ("reward", (1,), torch.float32), ("done", (1,), torch.uint8),
+                               ("done_reason", (1,), torch.uint8)], engine.device)
+            engine.bind_outputs(**m.views)
+            self._msg = m
+            self._host = torch.empty(m.nbytes, dtype=torch.uint8)
+            self._h = {k: v.numpy() for k, v in m.views_of(self._host).items()}
         self._cache = None      # (state [20], aux [6]) of the current step, fetched on the first attribute read: a script that reads
                                 # rc, vc, qc, wc, t, collided ... after every step pays one pair of device -> host copies, not ten
 
@@ -73,12 +82,16 @@ class RendezvousEnv(_EnvBase):
         self._act.copy_(torch.from_numpy(a.reshape(1, 6)))
         self._cache = None
         obs, rew, done = self.batch.step(self._act)
-        obs = obs.cpu().numpy()[0].copy()
-        rew = float(rew.cpu().numpy()[0])
-        done = bool(done.cpu().numpy()[0])
+        if self._msg is not None:
+            self._host.copy_(self._msg.flat)                                   # one message (synchronises)
+            obs, rew, done = self._h["obs"][0].copy(), float(self._h["reward"][0]), bool(self._h["done"][0])
+        else:
+            obs = obs.cpu().numpy()[0].copy()
+            rew = float(rew.cpu().numpy()[0])
+            done = bool(done.cpu().numpy()[0])
         if done and not self.quiet:                                             # :376-382
             s = self._now()[0]
-            reason = int(self.batch.done_reason.cpu().numpy()[0])
+            reason = int(self._h["done_reason"][0]) if self._msg is not None else int(self.batch.done_reason.cpu().numpy()[0])
             t_end = self.t
             t_end = int(t_end) if float(self.batch.params.dt).is_integer() else t_end
             print("Episode end | r = " + str(round(float(np.linalg.norm(s[0:3])), 2)).rjust(5) + " | t = " + str(t_end).rjust(4) +
