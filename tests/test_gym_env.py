@@ -154,3 +154,46 @@ def test_deepcopy_gives_an_independent_env_in_the_same_state():
     o1, r1, d1, _ = e.step(np.full(6, -0.5, np.float32))
     o2, r2, d2, _ = f.step(np.full(6, -0.5, np.float32))
     assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2 and f.t == 2.0
+
+
+REFERENCE_MC = "/root/reference/monte_carlo.py"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REFERENCE_MC), reason="needs the reference tree (build container only)")
+def test_the_reference_evaluate_loop_runs_unchanged_on_the_gym_object():
+    """Drop-in check of SURVEY §8b-i in the build container: the reference's OWN ``monte_carlo.evaluate(model, env, initial_state)``
+    (monte_carlo.py:94-207 — self-contained, NumPy only) is taken from its source text at test time, unmodified, and driven with
+    ``RendezvousEnv`` as ``env`` (oracle-backed engine: no GPU here) and ``MlpPolicy`` as ``model``.  Its 12 outputs for the first
+    rows of the published initial conditions must equal the reference's own re-run recorded in tests/golden/mc_reference_run.npz.
+    (Nothing of the reference is stored in the repo; the test is skipped where the reference tree does not exist.)"""
+    import os
+    import torch
+    from helpers import GOLDEN
+    from oracle_engine import OracleEngine
+    from reinforcement_learning_rendezvous_amd import monte_carlo as mc
+    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+    src = open(REFERENCE_MC).read()
+    start = src.index("def evaluate(model, env, initial_state):")
+    end = src.index('if __name__ == "__main__":', start)
+    scope = {"np": np}
+    exec(compile(src[start:end], REFERENCE_MC, "exec"), scope)          # the reference's function object, as written
+    evaluate = scope["evaluate"]
+    torch.set_num_threads(1)
+    model = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    env = RendezvousEnv(engine=OracleEngine(1, mc.make_eval_params(), storage="f64", on_done="continue", seed=0), quiet=True)
+    ics = load_golden("mc_initial_conditions.npz")["states"]
+    ref = load_golden("mc_reference_run.npz")
+    cols = [str(c) for c in ref["columns"]]
+    tol = dict(total_reward=5e-2, total_delta_v=1e-5, min_dist_from_koz=2e-4, pos_error=2e-5, vel_error=1e-5, att_error=5e-3,
+               rot_error=2e-5)          # torch-f32 vs NumPy-f32 policy arithmetic, as in test_oracle_golden.py
+    n_succ = n_coll = 0
+    for row in range(40):
+        s = ics[row]
+        out = evaluate(model, env, dict(rc=s[0:3], vc=s[3:6], qc=s[6:10], wc=s[10:13], qt=s[13:17], wt=s[17:20]))
+        assert list(out) == cols
+        for c in ("ep_len", "num_collisions", "collided", "num_successes", "succeeded"):
+            assert out[c] == ref["table"][row, cols.index(c)], (row, c)
+        for c, t in tol.items():
+            assert abs(out[c] - ref["table"][row, cols.index(c)]) <= t, (row, c, out[c], ref["table"][row, cols.index(c)])
+        n_succ += out["succeeded"]; n_coll += out["collided"]
+    assert n_succ == int(ref["table"][:40, cols.index("succeeded")].sum()) and n_coll == int(ref["table"][:40, cols.index("collided")].sum())
