@@ -12,7 +12,7 @@ from helpers import to_oracle_params
 
 class OracleEngine:
     def __init__(self, num_envs, params, storage="f64", on_done="reset", seed=0, env_id_offset=0, n_threads=1,
-                 numpy_legacy=False):
+                 numpy_legacy=False, tape=None):
         self.num_envs = int(num_envs)
         self.params = params.copy()
         self.device = torch.device("cpu")
@@ -20,7 +20,8 @@ class OracleEngine:
             self.num_envs, to_oracle_params(params),
             storage=oracle.STORAGE_F32 if storage == "f32" else oracle.STORAGE_F64,
             on_done={"halt": oracle.ON_DONE_HALT, "continue": oracle.ON_DONE_NOTHING}.get(on_done, oracle.ON_DONE_RESET),
-            seed=seed, env_id_offset=env_id_offset, n_threads=n_threads, numpy_legacy=numpy_legacy)
+            seed=seed, env_id_offset=env_id_offset, n_threads=n_threads, numpy_legacy=numpy_legacy,
+            **({} if tape is None else {"tape": np.asarray(tape, dtype=np.float64)}))      # reset tape [depth, N, 20]: recorded initial states
         self._orc_halts = on_done == "halt"
         self.obs = self.reward = self.done = None
         self.terminal_obs = self.episode_return = self.episode_length = self.done_reason = self.diag = None

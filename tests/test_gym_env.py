@@ -197,3 +197,81 @@ def test_the_reference_evaluate_loop_runs_unchanged_on_the_gym_object():
             assert abs(out[c] - ref["table"][row, cols.index(c)]) <= t, (row, c, out[c], ref["table"][row, cols.index(c)])
         n_succ += out["succeeded"]; n_coll += out["collided"]
     assert n_succ == int(ref["table"][:40, cols.index("succeeded")].sum()) and n_coll == int(ref["table"][:40, cols.index("collided")].sum())
+
+
+REFERENCE_TRAJ = "/root/reference/save_new_trajectory.py"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REFERENCE_TRAJ), reason="needs the reference tree (build container only)")
+def test_the_reference_trajectory_recorder_runs_unchanged_on_the_gym_object(capsys):
+    """As above for ``save_new_trajectory.evaluate(model, env, args)`` (save_new_trajectory.py:35-204): the reference's function, from
+    its source text, records an episode of ``RendezvousEnv`` — ``reset()``, ``get_observation``, every state attribute, ``get_errors``,
+    ``check_collision`` / ``check_success`` / ``dist_from_koz`` / ``collided`` / ``t`` after every step — and must return the arrays the
+    reference recorded for the same three initial states (tests/golden/eval_reference.npz; the env's reset replays them from a tape)."""
+    import os
+    import pickle
+    import types
+    import torch
+    from helpers import GOLDEN
+    from oracle_engine import OracleEngine
+    from reinforcement_learning_rendezvous_amd.params import make_params
+    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+    src = open(REFERENCE_TRAJ).read()
+    start = src.index("def evaluate(model, env, args):")
+    end = src.index("def get_args():", start)
+    scope = {"np": np, "os": os, "pickle": pickle, "print_state": lambda env: None}      # print_state: a table printer (environment_utils.py:100)
+    exec(compile(src[start:end], REFERENCE_TRAJ, "exec"), scope)
+    evaluate = scope["evaluate"]
+    torch.set_num_threads(1)
+    model = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    g = load_golden("eval_reference.npz")
+    for j in range(3):
+        s0 = g[f"traj{j}_state0"]
+        env = RendezvousEnv(engine=OracleEngine(1, make_params(), storage="f64", on_done="continue", tape=s0[None, None, :]), quiet=True)
+        data = evaluate(model, env, types.SimpleNamespace(save=False))       # note: like the reference's, this env object is spent afterwards
+        for k in ("rc", "vc", "qc", "wc", "qt", "wt", "a", "rew", "errors", "t"):
+            want = g[f"traj{j}_{k}"]
+            assert data[k].shape == want.shape, (j, k, data[k].shape, want.shape)
+            np.testing.assert_array_equal(np.isnan(data[k]), np.isnan(want), err_msg=f"{j} {k}")
+            np.testing.assert_allclose(np.nan_to_num(data[k]), np.nan_to_num(want), rtol=0, atol=2e-4, err_msg=f"{j} {k}")
+        d_koz, collisions, successes = g[f"traj{j}_scalars"]
+        assert data["d_koz"] == pytest.approx(d_koz, abs=1e-4)
+        assert data["collisions"] == int(collisions) and data["successes"] == int(successes)
+    capsys.readouterr()
+
+
+REFERENCE_CB = "/root/reference/custom/custom_callbacks.py"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(REFERENCE_CB), reason="needs the reference tree (build container only)")
+def test_the_reference_training_callback_evaluation_runs_unchanged_on_the_gym_object(capsys):
+    """And for ``CustomWandbCallback.evaluate_policy(self)`` (custom/custom_callbacks.py:186-300), the evaluation the reference runs
+    during training: the method body, from its source text, with ``self.env = RendezvousEnv`` (24 resets replayed from the recorded
+    tape), ``self.model = MlpPolicy``, ``self.n_evals = 24`` — ``target2lvlh(rd)``, ``get_pos_error``, ``get_attitude_error``,
+    ``check_collision``, ``t``, ``success``, ``rc``, ``total_delta_v`` / ``total_delta_w``, ``dt`` — must log the 12 means the
+    reference logged (tests/golden/eval_reference.npz)."""
+    import os
+    import textwrap
+    import types
+    import torch
+    from helpers import GOLDEN
+    from oracle_engine import OracleEngine
+    from reinforcement_learning_rendezvous_amd.params import make_params
+    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
+    src = open(REFERENCE_CB).read()
+    start = src.index("    def evaluate_policy(self):")
+    end = src.index("        return output", start) + len("        return output")
+    scope = {"np": np}
+    exec(compile(textwrap.dedent(src[start:end]), REFERENCE_CB, "exec"), scope)
+    torch.set_num_threads(1)
+    g = load_golden("eval_reference.npz")
+    env = RendezvousEnv(engine=OracleEngine(1, make_params(), storage="f64", on_done="continue", tape=g["cb_tape"][:, None, :]), quiet=True)
+    me = types.SimpleNamespace(model=MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz")), env=env, n_evals=24)
+    out = scope["evaluate_policy"](me)
+    ref = dict(zip([str(k) for k in g["cb_metric_names"]], g["cb_metrics"]))
+    assert list(out) == list(ref)
+    for k in ("ep_len", "ep_success", "ep_collision_percentage", "ep_time_of_first_collision", "%_collided_episodes", "%_successfull_episodes"):
+        assert out[k] == pytest.approx(ref[k], rel=1e-12), k                  # step counts: exact
+    for k in ("ep_rew", "ep_dist", "ep_delta_v", "ep_delta_w", "ep_min_pos_error", "ep_avg_att_error"):
+        assert out[k] == pytest.approx(ref[k], rel=2e-5), k                   # NumPy-f32 vs torch-f32 policy arithmetic
+    capsys.readouterr()
