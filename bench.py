@@ -26,6 +26,7 @@ One JSON line is printed by rank 0.  Besides the contract keys it carries
                  bounded sample of the same workload (rank 0, N=1 only).
   policy_rollout: informational — the same envs driven by the 17-64-64-6 tanh MLP policy (BASELINE config 3:
                  forward + Gaussian sample + clip in PyTorch-ROCm, then the step kernel), N=1 only.
+  config1_single_env_gym_object: informational — BASELINE config 1 (one env, 1000 steps) through RendezvousEnv, the reference's Gym object.
 """
 import argparse
 import json
