@@ -77,8 +77,12 @@ typedef enum RdvKernelVariant {
   RDV_VARIANT_AUTO = 0,
   RDV_VARIANT_FUSED = 1,  /* one wave does the transition of its 64 envs; the workgroup's four waves share the resets of its finished envs by part */
   RDV_VARIANT_SPLIT = 2,  /* step waves + service waves that precompute every env's next initial state beside them */
-  RDV_VARIANT_FUSED_INLANE = 3  /* as FUSED, but every finished lane runs its whole reset itself (divergent); also what the evaluator
+  RDV_VARIANT_FUSED_INLANE = 3, /* as FUSED, but every finished lane runs its whole reset itself (divergent); also what the evaluator
                                    build (diag / eval outputs), general rigid bodies and the first step after rdv_set_state run */
+  RDV_VARIANT_FUSED_TILES = 4   /* FUSED as a tile loop: ~3 workgroups per CU walk the batch in tiles of 256 envs, the next tile's inputs
+                                   requested while the current one computes (csrc/rdv_tiles.hip).  Never chosen by AUTO: measured
+                                   3-8 % slower than FUSED at every size.  With on_done = HALT or a reset tape
+                                   it runs FUSED */
 } RdvKernelVariant;
 
 /*

@@ -15,7 +15,7 @@ CSRC = os.path.join(_PKG, "csrc")
 
 STORAGE_F32, STORAGE_F64 = 0, 1
 ON_DONE_RESET, ON_DONE_HALT, ON_DONE_CONTINUE = 0, 1, 2
-VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT, VARIANT_FUSED_INLANE = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_FUSED, VARIANT_SPLIT, VARIANT_FUSED_INLANE, VARIANT_FUSED_TILES = 0, 1, 2, 3, 4
 OBS_DIM, ACT_DIM, STATE_DIM, DIAG_DIM, AUX_DIM, EVAL_DIM = 17, 6, 20, 8, 8, 32
 
 ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVICE", -3: "RDV_ERR_HIP",

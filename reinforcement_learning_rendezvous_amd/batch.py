@@ -18,14 +18,15 @@ from .params import EnvParams, make_params
 
 _STORAGE = {"f32": N.STORAGE_F32, "f64": N.STORAGE_F64, N.STORAGE_F32: N.STORAGE_F32, N.STORAGE_F64: N.STORAGE_F64}
 _ON_DONE = {"reset": N.ON_DONE_RESET, "halt": N.ON_DONE_HALT, "continue": N.ON_DONE_CONTINUE}
-_VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT, "fused_inlane": N.VARIANT_FUSED_INLANE}
+_VARIANT = {"auto": N.VARIANT_AUTO, "fused": N.VARIANT_FUSED, "split": N.VARIANT_SPLIT, "fused_inlane": N.VARIANT_FUSED_INLANE,
+            "fused_tiles": N.VARIANT_FUSED_TILES}
 
 
 class RendezvousBatch:
     def __init__(self, num_envs, params: EnvParams = None, device="cuda:0", storage="f32", on_done="reset", seed=0,
                  env_id_offset=0, variant="auto", **env_kwargs):
         """``env_kwargs`` are the keyword arguments of the reference constructor (rendezvous_env.py:17-37).
-        ``variant`` ("auto" | "fused" | "split" | "fused_inlane") selects the step kernel layout; results do not depend on it."""
+        ``variant`` ("auto" | "fused" | "split" | "fused_inlane" | "fused_tiles") selects the step kernel layout; results do not depend on it."""
         if params is not None and env_kwargs:
             raise TypeError("pass either params or the reference constructor's keyword arguments, not both")
         self.params = params.copy() if params is not None else make_params(**env_kwargs)

@@ -66,6 +66,7 @@ struct DevParams {
   // reset (rendezvous_env.py:229-258); nominal quaternions pre-normalised (quat_product does it, quaternions.py:159-160)
   double nominal_rc0[3], nominal_vc0[3], nominal_qc0[4], nominal_wc0[3], nominal_qt0[4], nominal_wt0[3];
   double rc0_range, vc0_range, qc0_range, wc0_range, qt0_range, wt0_range;
+  int32_t qc0_tiny, qt0_tiny;             // (range / 2)^2 <= kTinyU: a reset's attitude deviation uses the short series (deviate)
   // general rigid bodies (rdv_set_rigid_body; read by the kGeneral kernels only): inertia tensor, its inverse (row-major) and the
   // constant body torque of the chaser [0] and the target [1]; tolerances of the env's solve_ivp calls (:567-568)
   double body_inertia[2][9], body_inv_inertia[2][9], body_torque[2][3];
@@ -137,15 +138,40 @@ __device__ __forceinline__ void cos_sinc_small(double u, double& c, double& sc) 
   q = fma(q, u, -1.0 / 6.0);
   sc = fma(q, u, 1.0);
 }
+// The same two series cut after u^4, for u <= kTinyU = 2^-7 (t <= 0.088 rad = 5 deg): the first dropped terms are u^5/10! < 8e-18 and
+// u^5/11! < 8e-19, a twentieth of an ulp of results near 1.  Every attitude step inside the observation Box is in this range
+// (|w| dt/2 <= 10 deg/s * dt/2), as is a reset's chaser attitude: 8 Horner steps instead of 18 (and as many 64-bit literals less).
+constexpr double kTinyU = 0.0078125;
+// (The eight coefficients as SGPR operands read from the parameter block — one s_load instead of sixteen v_mov — were measured in round 4:
+//  24 instructions fewer per call and 0.09 us SLOWER per launch at 65,536 envs; the scalar load's latency lands on the step wave's chain.
+//  profiles/r04_isa_diet.txt)
+__device__ __forceinline__ void cos_sinc_tiny(double u, double& c, double& sc) {
+  double p = 1.0 / 40320.0;                        //  1/8!
+  p = fma(p, u, -1.0 / 720.0);                     // -1/6!
+  p = fma(p, u, 1.0 / 24.0);                       //  1/4!
+  p = fma(p, u, -0.5);
+  c = fma(p, u, 1.0);
+  double q = 1.0 / 362880.0;                       //  1/9!
+  q = fma(q, u, -1.0 / 5040.0);                    // -1/7!
+  q = fma(q, u, 1.0 / 120.0);                      //  1/5!
+  q = fma(q, u, -1.0 / 6.0);
+  sc = fma(q, u, 1.0);
+}
 // Larger angles (never reached inside the observation Box: |w| <= 10 deg/s): halve the angle until it is small,
 // then apply cos 2x = 2cos^2 x - 1, sinc 2x = sinc x cos x once per halving (error doubles per halving).
-__device__ __forceinline__ void cos_sinc(double u, double& c, double& sc) {
+__device__ __forceinline__ void cos_sinc_large(double u, double& c, double& sc) {
   int halvings = 0;
 #pragma clang loop unroll(disable)
   while (__builtin_expect(u > kSmallU && halvings < 64, 0)) { u *= 0.25; ++halvings; }
   cos_sinc_small(u, c, sc);
 #pragma clang loop unroll(disable)
   for (int h = 0; h < halvings; ++h) { sc = sc * c; c = fma(2.0 * c, c, -1.0); }
+}
+// Which series a lane uses is a function of ITS u alone (a per-lane branch; never of what the other lanes of its wave hold), so an env
+// gets the same bits from every kernel, whatever that kernel's grouping of envs into waves.
+__device__ __forceinline__ void cos_sinc(double u, double& c, double& sc) {
+  if (__builtin_expect(u <= kTinyU, 1)) cos_sinc_tiny(u, c, sc);
+  else cos_sinc_large(u, c, sc);
 }
 
 // R(q) of quaternions.py:48-68 (which normalises q first, :57)
@@ -506,7 +532,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
 }
 // 21-bit uniform in (0,1).  A reset needs 24 uniforms = 504 bits = 4 Philox blocks (three 21-bit fields per 64 bits);
 // 32-bit integer multiplies are quarter-rate on CDNA, so the block count is what a reset costs.
-__device__ __forceinline__ double u21(uint32_t field) { return ((double)field + 0.5) * (1.0 / 2097152.0); }
+// ((field + 0.5) / 2^21 as ONE fma: field * 2^-21 + 2^-22 — every intermediate of either form is exact, so the same bits)
+__device__ __forceinline__ double u21(uint32_t field) { return fma((double)field, 1.0 / 2097152.0, 0.5 / 2097152.0); }
 
 // general.py:248-254: uniform(-1,1,3) normalised (cube-normalised direction, as the reference)
 __device__ __forceinline__ void unit_vector(double u0, double u1, double u2, double* o) {
@@ -517,10 +544,13 @@ __device__ __forceinline__ void unit_vector(double u0, double u1, double u2, dou
 // quat_product(rot2quat(axis, theta), nominal) (:239/:255, quaternions.py:11-27, :149-170).  `axis` is a unit vector and
 // `nominal` is pre-normalised, so the reference's re-normalisations of axis, of the rotation quaternion and of both
 // factors are identities up to rounding and are dropped; as in the reference, the product itself is not normalised.
-__device__ __forceinline__ void deviate(const double* axis, double theta, const double* nominal, double* o) {
+// `tiny`: wave-uniform, from the PARAMETERS (0 <= theta <= the sampling range, and (range/2)^2 <= kTinyU) — so that the series does
+// not depend on what a wave happens to hold, and a wave of mostly large angles (the target's 45 deg range) does not run both.
+__device__ __forceinline__ void deviate(const double* axis, double theta, const double* nominal, bool tiny, double* o) {
   const double half = 0.5 * theta;
   double c, sc;
-  cos_sinc(half * half, c, sc);
+  if (tiny) cos_sinc_tiny(half * half, c, sc);
+  else cos_sinc_large(half * half, c, sc);
   const double s = sc * half;
   const double a[4] = {c, axis[0] * s, axis[1] * s, axis[2] * s};
   const double* b = nominal;
@@ -591,7 +621,7 @@ __device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_
     if (do_c) {
       const double theta_c = P.qc0_range * u[8];                            // :237
       unit_vector(u[9], u[10], u[11], dir);                                 // :238
-      deviate(dir, theta_c, P.nominal_qc0, e.qc);                           // :239, :255
+      deviate(dir, theta_c, P.nominal_qc0, P.qc0_tiny != 0, e.qc);                           // :239, :255
       unit_vector(u[12], u[13], u[14], dir);                                // :242
       { const double m = P.wc0_range * u[15];
 #pragma unroll
@@ -601,7 +631,7 @@ __device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_
     if (do_qt) {
       const double theta_t = P.qt0_range * u[16];                           // :245
       unit_vector(u[17], u[18], u[19], dir);                                // :246
-      deviate(dir, theta_t, P.nominal_qt0, e.qt);                           // :247, :257
+      deviate(dir, theta_t, P.nominal_qt0, P.qt0_tiny != 0, e.qt);                           // :247, :257
     }
     if (do_wt) {
       unit_vector(u[20], u[21], u[22], dir);                                // :250
@@ -675,8 +705,12 @@ struct StepResult {   // (the observation goes to the caller's sink: see observa
 };
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
-template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink>
-__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink) {
+// `mid()` is called once the chaser side is finished and the attitude error's table entry has been requested — the last load of a
+// transition: a kernel that fetches ahead (step_kernel_tiles) issues its look-ahead loads there, BEHIND that entry in the in-order
+// vector-memory counter, so that waiting for the entry does not mean waiting for the look-ahead.
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink, typename Hook = NoHook>
+__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink, Hook&& mid = Hook()) {
   const ST tag = ST(0);
   // :201-202, :333 need the action only through these two float32 sums: formed here, so that the six action registers die with the
   // impulses below instead of living to the end of the transition
@@ -712,6 +746,7 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   double inv_dist;
   derive_chaser(P, e, d, inv_dist);
   const double att = attitude_error_of(P, d.k_att);
+  mid();
   // target side (:184)
   if (kGeneral) {
     integrate_attitude_rk45(e.qt, e.wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);
@@ -748,6 +783,9 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   r.reward = (float)rew;
   r.reward64 = rew;
   // :205, :355-386
+  // Box.contains (:367): outside <=> some |v| > 1 or NaN <=> the largest (bits & 0x7fffffff) exceeds the bits of 1.0f (NaNs lie above
+  // infinity there).  One integer maximum over the 17 elements and one comparison, instead of 17 float comparisons each writing a
+  // lane mask that the scalar unit then has to OR together.
   bool outside = false;
   observation_to(P, e, [&](int j, float v) {
     outside |= !(fabsf(v) <= 1.0f);                                                    // Box.contains; NaN -> outside

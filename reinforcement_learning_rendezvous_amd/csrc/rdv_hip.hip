@@ -27,318 +27,10 @@
 
 #include "../../include/rdv.h"
 
+#include "rdv_kernels.h"
+#include "rdv_tiles.h"
+
 namespace rdv {
-
-#ifndef RDV_PARTS_WAVES
-// amdgpu_waves_per_eu lower bound of step_kernel_parts<float>.  With 3 the allocator lands at 128 registers = FOUR waves per SIMD
-// without scratch; asked for 4 outright it squeezes to 126 and spills 3 dwords (tools/resource_table.py; tests/test_abi.py holds the
-// build to "<= 128 VGPRs, ScratchSize 0").  tools/lib_ab_large.py times the alternatives.
-#define RDV_PARTS_WAVES 3
-#endif
-constexpr int kBlock = 256;             // 4 waves per workgroup
-constexpr int kWave = 64;
-constexpr int kChunks = 7;
-constexpr int kStatWords = 16;          // 128-byte slot per wave
-// Fused kernels: each XCD walks a contiguous eighth of the batch (instead of every 8th workgroup of the whole batch) when the batch
-// is a multiple of 65,536 envs up to 3 M — an empirical rule (tools/xcd_map_ab.py, profiles/r02_xcd_order_ab.txt; order toggled per
-// launch on one allocation): -10 % at 524,288 envs (42.2 -> 37.8 us), -9 % at 786,432, -7 % at 262,144, -5 % at 1 M, -3 % at 196,608
-// and 2 M, -1 % at 3 M; +2 % at 4 M, +3.5 % at 8 M; and off those sizes it does not pay: +8 % at 1,000,000, +6 % at 262,400, -4 % at
-// 528,384, 0 at 500,000.  Padding or skewing the arrays instead recovers less (chunk_stride).  RDV_XCD_ORDER=0|1 in the
-// environment at rdv_create forces it off / on (diagnostics).
-constexpr int64_t kXcdOrderMaxEnvs = 3145728;
-static inline bool xcd_order_by_size(int64_t n) { return n <= kXcdOrderMaxEnvs && n % 65536 == 0; }
-// Fused kernel: the observation rows leave with non-temporal stores up to this size (tools/lib_ab.py, same box, alternating child
-// processes, us per launch plain -> streamed): 98,304 envs 11.02 -> 10.69, 131,072 11.48 -> 11.19, 196,608 14.8 -> 13.6, 262,144
-// 22.57 -> 21.24, 327,680 26.98 -> 26.57, 393,216 30.9 -> 30.1; 458,752 and 524,288 +-2 % either way, 786,432 57.7 -> 61.6 (worse).
-constexpr int64_t kStreamRowsMaxEnvs = 393216;
-constexpr int64_t kSplitAutoMaxEnvs = 65536;    // measured crossover (tools/n_sweep.py, profiles/r02_n_sweep_parts.csv): split wins up to one 256-env workgroup per CU
-enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
-       ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
-
-template <typename ST> struct Vec4;
-template <> struct Vec4<float> { using type = float4; };
-template <> struct Vec4<double> { using type = double4; };
-
-__device__ __forceinline__ float u2s(uint32_t u, float) { return __uint_as_float(u); }
-__device__ __forceinline__ double u2s(uint32_t u, double) { return __longlong_as_double((long long)u); }
-__device__ __forceinline__ uint32_t s2u(float s) { return __float_as_uint(s); }
-__device__ __forceinline__ uint32_t s2u(double s) { return (uint32_t)__double_as_longlong(s); }
-
-template <typename ST>
-__device__ __forceinline__ void load_env(const typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i, Env& e) {
-  using V = typename Vec4<ST>::type;
-  const V c0 = ws[0 * cs + i], c1 = ws[1 * cs + i], c2 = ws[2 * cs + i], c3 = ws[3 * cs + i], c4 = ws[4 * cs + i],
-          c5 = ws[5 * cs + i], c6 = ws[6 * cs + i];
-  e.rc[0] = c0.x; e.rc[1] = c0.y; e.rc[2] = c0.z; e.vc[0] = c0.w;
-  e.vc[1] = c1.x; e.vc[2] = c1.y; e.wc[0] = c1.z; e.wc[1] = c1.w;
-  e.wc[2] = c2.x; e.bubble = c2.y; e.sum_dv = c2.z; e.sum_dw = c2.w;
-  e.qc[0] = c3.x; e.qc[1] = c3.y; e.qc[2] = c3.z; e.qc[3] = c3.w;
-  e.qt[0] = c4.x; e.qt[1] = c4.y; e.qt[2] = c4.z; e.qt[3] = c4.w;
-  e.ep_ret = c5.x; e.k = (int32_t)s2u(c5.y); e.flags = s2u(c5.z); e.episode = s2u(c5.w);
-  e.wt[0] = c6.x; e.wt[1] = c6.y; e.wt[2] = c6.z;
-}
-
-// registers -> the seven storage chunks of one env
-template <typename ST>
-__device__ __forceinline__ void pack_env(const Env& e, typename Vec4<ST>::type* c) {
-  const ST t = ST(0);
-  c[0].x = (ST)e.rc[0]; c[0].y = (ST)e.rc[1]; c[0].z = (ST)e.rc[2]; c[0].w = (ST)e.vc[0];
-  c[1].x = (ST)e.vc[1]; c[1].y = (ST)e.vc[2]; c[1].z = (ST)e.wc[0]; c[1].w = (ST)e.wc[1];
-  c[2].x = (ST)e.wc[2]; c[2].y = (ST)e.bubble; c[2].z = (ST)e.sum_dv; c[2].w = (ST)e.sum_dw;
-  c[3].x = (ST)e.qc[0]; c[3].y = (ST)e.qc[1]; c[3].z = (ST)e.qc[2]; c[3].w = (ST)e.qc[3];
-  c[4].x = (ST)e.qt[0]; c[4].y = (ST)e.qt[1]; c[4].z = (ST)e.qt[2]; c[4].w = (ST)e.qt[3];
-  c[5].x = (ST)e.ep_ret; c[5].y = u2s((uint32_t)e.k, t); c[5].z = u2s(e.flags, t); c[5].w = u2s(e.episode, t);
-  c[6].x = (ST)e.wt[0]; c[6].y = (ST)e.wt[1]; c[6].z = (ST)e.wt[2]; c[6].w = ST(0);
-}
-template <typename ST>
-__device__ __forceinline__ void store_chunks(typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i,
-                                             const typename Vec4<ST>::type* c, bool with_wt) {
-#pragma unroll
-  for (int k = 0; k < 6; ++k) ws[k * cs + i] = c[k];
-  if (with_wt) ws[6 * cs + i] = c[6];
-}
-template <typename ST>
-__device__ __forceinline__ void store_env(typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i, const Env& e, bool with_wt) {
-  typename Vec4<ST>::type c[7];
-  pack_env<ST>(e, c);
-  store_chunks<ST>(ws, cs, i, c, with_wt);
-}
-
-// Diagnostic build only (-DRDV_STAMPS, tools/stamp_profile.py): s_memtime stamps at the phase boundaries of the split
-// kernel, written to a buffer nothing else reads.  In the product build these macros expand to nothing.
-#ifdef RDV_STAMPS
-#define RDV_STAMP_DECL unsigned long long stamp_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; stamp_[8] = __builtin_amdgcn_s_memrealtime();
-#define RDV_STAMP(k)                                   \
-  do {                                                 \
-    __builtin_amdgcn_sched_barrier(0);                 \
-    stamp_[k] = __builtin_readcyclecounter();          \
-    __builtin_amdgcn_sched_barrier(0);                 \
-  } while (0)
-#define RDV_STAMP_FLUSH(wave_id)                                                              \
-  if (A.stamps && lane == 0) {                                                                \
-    stamp_[9] = __builtin_amdgcn_s_memrealtime();                                           \
-    for (int s_ = 0; s_ < 10; ++s_) A.stamps[(uint64_t)(wave_id) * 10 + s_] = stamp_[s_];     \
-  }
-#else
-#define RDV_STAMP_DECL
-#define RDV_STAMP(k)
-#define RDV_STAMP_FLUSH(wave_id)
-#endif
-
-struct StepArgs {
-  void* ws;                 // chunk arrays
-  uint64_t* stats;          // [n_waves][16]
-  const float* actions;     // [N,6]
-  float* obs;               // [N,17]
-  float* reward;            // [N]
-  uint8_t* done;            // [N]
-  float* terminal_obs;      // nullable
-  float* episode_return;    // nullable
-  int32_t* episode_length;  // nullable
-  uint8_t* done_reason;     // nullable
-  double* diag;             // nullable [N,8]
-  double* eval;             // nullable [N,32]: per-env evaluation accumulators (eval_accumulate)
-  const double* tape;       // nullable [depth][N][20]
-  int64_t n;
-  int64_t cs;               // chunk stride in envs: chunk c of env i is vector c * cs + i of the workspace (chunk_stride)
-  uint64_t seed;
-  uint64_t env_id_offset;
-  int32_t tape_depth;
-  int32_t on_done;
-  void* prep;               // prepared next-episode states of the persistent kernels (csrc/rdv_slots.h): one record per env
-  uint32_t* prep_tag;       // [N]
-  int32_t xcd_per;          // fused kernels: workgroups per XCD region (0: plain block order)
-  int32_t stream_rows;      // fused kernels: store the observation rows non-temporally (kStreamRowsMaxEnvs)
-#ifdef RDV_STAMPS
-  unsigned long long* stamps;
-#endif
-};
-
-// LDS exchanged inside ONE wave (wave-private region): LDS operations of a wave execute in issue order, so only the
-// compiler has to be kept from moving the reads above the writes.
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// actions [64,6] of one wave: every lane loads its own row straight into registers, three 8-byte loads at a 24-byte lane stride (the
-// wave's rows are 1.5 KB contiguous, so the three instructions touch the same twelve lines a staged, lane-contiguous copy would).
-// Round 1 staged the rows through LDS for lane-contiguous loads; the round trip (write, fence, six reads) sat on the critical chain:
-// 7.14 -> 6.84 us per launch at 65,536 envs, 13.5 -> 12.8 at 196,608 (tools/lib_ab.py).
-__device__ __forceinline__ void load_actions(const float* __restrict__ actions, int64_t wave_base, int lane, bool active, float* a) {
-  const float* row = actions + (wave_base + lane) * RDV_ACT_DIM;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float2 v = make_float2(0.0f, 0.0f);
-    if (active) v = *reinterpret_cast<const float2*>(row + 2 * k);
-    a[2 * k] = v.x; a[2 * k + 1] = v.y;
-  }
-}
-
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-// observations [64,17] of one wave: staged rows in LDS -> contiguous 16-byte-per-lane global stores
-// (`aligned`: dst is 16-byte aligned — always for [N,17] rows of a 64-env wave, for row t of a [T,N,17] tape only if N % 4 == 0)
-// kStream: non-temporal stores (the split kernel: see there)
-template <bool kStream = false>
-__device__ __forceinline__ void store_obs_rows(float* __restrict__ obs, int64_t wave_base, int64_t rows, int lane, const float* wl,
-                                               bool aligned = true) {
-  if (rows <= 0) return;
-  float* dst = obs + wave_base * RDV_OBS_DIM;
-  if (rows == kWave && aligned) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int q = k * kWave + lane;
-      if (kStream) __builtin_nontemporal_store(*reinterpret_cast<const nt_f4*>(wl + 4 * q), reinterpret_cast<nt_f4*>(dst + 4 * q));
-      else *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
-    }
-    if (lane < 16) {
-      const int q = 4 * kWave + lane;
-      if (kStream) __builtin_nontemporal_store(*reinterpret_cast<const nt_f4*>(wl + 4 * q), reinterpret_cast<nt_f4*>(dst + 4 * q));
-      else *reinterpret_cast<float4*>(dst + 4 * q) = *reinterpret_cast<const float4*>(wl + 4 * q);
-    }
-  } else {   // ragged tail wave
-    const int64_t valid = rows * RDV_OBS_DIM;
-    for (int j = 0; j < RDV_OBS_DIM; ++j) {
-      const int idx = j * kWave + lane;
-      if (idx < valid) dst[idx] = wl[idx];
-    }
-  }
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
-// Wave-wide sums by DPP (no LDS, no loop): four row_shr steps inside each row of 16 lanes, then row_bcast:15 / :31 carry the row
-// totals upwards; lane 63 ends with the sum of all 64 lanes.  A fixed tree: the fp64 sums are reproducible run to run and the same
-// in every kernel (they all reduce through here).  Round 1 walked the finished lanes with v_readlane in a scalar loop — serial,
-// ~0.7 us of the step wave at 65,536 envs (ablation: profiles/r02_ablation_split.txt).
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ int dpp_shift_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xf, false); }
-template <int kCtrl, int kRowMask>
-__device__ __forceinline__ double dpp_step_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
-  return v + __hiloint2double(hi, lo);      // lanes outside the row mask / without a source lane add +0.0
-}
-__device__ __forceinline__ double wave_sum_f64(double v) {
-  v = dpp_step_f64<0x111, 0xf>(v);   // row_shr:1
-  v = dpp_step_f64<0x112, 0xf>(v);   // row_shr:2
-  v = dpp_step_f64<0x114, 0xf>(v);   // row_shr:4
-  v = dpp_step_f64<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of each row holds the row's sum
-  v = dpp_step_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-  v = dpp_step_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's sum
-  return readlane_f64(v, 63);
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {
-  v += dpp_shift_i32<0x111, 0xf>(v);
-  v += dpp_shift_i32<0x112, 0xf>(v);
-  v += dpp_shift_i32<0x114, 0xf>(v);
-  v += dpp_shift_i32<0x118, 0xf>(v);
-  v += dpp_shift_i32<0x142, 0xa>(v);
-  v += dpp_shift_i32<0x143, 0xc>(v);
-  return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ uint64_t stats_preload(const uint64_t* __restrict__ slot, int lane) {
-  return lane < 12 ? slot[lane] : 0ull;
-}
-// Episode statistics of one wave of envs, as wavefront reductions: ballot + popcount for the counters, DPP sums over the finished
-// lanes (the others contribute zero) for episode length, return and the two delta-v totals.  Lanes 0..11 then write the wave's
-// private 128-byte slot; `pre` is that slot's previous content, loaded by lanes 0..11 at kernel entry so that no memory latency
-// is paid here.
-__device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, uint64_t pre, int lane, bool stepped, bool fin,
-                                             int reason, uint32_t flags, int k, double ep_ret, double sum_dv, double sum_dw) {
-  const unsigned long long m_step = __ballot(stepped);
-  const unsigned long long m_fin = __ballot(fin);
-  if (m_step == 0ull) return;   // wave-uniform
-  if (m_fin != 0ull) {
-    const unsigned long long m_succ = __ballot(fin && (flags >> SUCCESS_SHIFT) != 0u);
-    const unsigned long long m_coll = __ballot(fin && (flags & FLAG_COLLIDED));
-    const unsigned long long m_r1 = __ballot(fin && reason == 1), m_r2 = __ballot(fin && reason == 2);
-    const unsigned long long m_r3 = __ballot(fin && reason == 3), m_r4 = __ballot(fin && reason == 4);
-    const int s_len = wave_sum_i32(fin ? k : 0);
-    const double s_ret = wave_sum_f64(fin ? ep_ret : 0.0);
-    const double s_dv = wave_sum_f64(fin ? sum_dv : 0.0);
-    const double s_dw = wave_sum_f64(fin ? sum_dw : 0.0);
-    if (lane < 12) {
-      // straight-line selects (a switch on the lane id compiles to a tree of exec-masked branches)
-      uint32_t iv = (uint32_t)__popcll(m_step);
-      iv = lane == ST_EPISODES ? (uint32_t)__popcll(m_fin) : iv;
-      iv = lane == ST_SUCCESS ? (uint32_t)__popcll(m_succ) : iv;
-      iv = lane == ST_COLLIDED ? (uint32_t)__popcll(m_coll) : iv;
-      iv = lane == ST_REASON0 ? (uint32_t)__popcll(m_r1) : iv;
-      iv = lane == ST_REASON1 ? (uint32_t)__popcll(m_r2) : iv;
-      iv = lane == ST_REASON2 ? (uint32_t)__popcll(m_r3) : iv;
-      iv = lane == ST_REASON3 ? (uint32_t)__popcll(m_r4) : iv;
-      iv = lane == ST_SUM_LEN ? (uint32_t)s_len : iv;
-      double dv = s_ret;
-      dv = lane == ST_SUM_DV ? s_dv : dv;
-      dv = lane == ST_SUM_DW ? s_dw : dv;
-      const uint64_t as_int = pre + iv;
-      const uint64_t as_real = (uint64_t)__double_as_longlong(__longlong_as_double((long long)pre) + dv);
-      slot[lane] = lane <= ST_SUM_LEN ? as_int : as_real;
-    }
-  } else if (lane == 0) {
-    slot[ST_STEPS] = pre + __popcll(m_step);
-  }
-}
-
-// per-env outputs of a transition (coalesced 4-/1-byte stores; the sparse ones only where an episode ended).  `row`: the lane's
-// staged observation row (LDS), which still holds the terminal observation here — read back by the ~5 % of lanes whose episode ended
-template <bool kTerminalObs>
-__device__ __forceinline__ void store_step_outputs(const StepArgs& A, int64_t i, bool active, bool fin, const StepResult& r,
-                                                   const Env& e, const float* row) {
-  if (active) {
-    A.reward[i] = r.reward;
-    A.done[i] = (uint8_t)r.done;
-    if (A.done_reason)   // reason | collided-in-episode << 4 | succeeded-in-episode << 5 (the flag bits only where done)
-      A.done_reason[i] = (uint8_t)(r.reason | ((fin && (e.flags & FLAG_COLLIDED)) ? 16 : 0) |
-                                   ((fin && (e.flags >> SUCCESS_SHIFT) != 0u) ? 32 : 0));
-  }
-  if (fin) {
-    if (kTerminalObs && A.terminal_obs) {
-      float* t = A.terminal_obs + i * RDV_OBS_DIM;
-#pragma unroll
-      for (int j = 0; j < RDV_OBS_DIM; ++j) t[j] = row[j];
-    }
-    if (A.episode_return) A.episode_return[i] = (float)e.ep_ret;
-    if (A.episode_length) A.episode_length[i] = e.k;
-  }
-}
-
-// step one lane's env (or report a halted one); returns whether a transition was executed.  The observation goes to `sink(j, v)`
-// element by element (zeros for a lane without an env): see observation_to.
-template <typename ST, bool kDiag, bool kGeneral = false, bool kRaw = false, typename Sink>
-__device__ __forceinline__ bool advance(const StepArgs& A, const DevParams& P, int64_t i, bool active, Env& e, const float* a,
-                                        StepResult& r, Sink&& sink) {
-  r.done = 0; r.reason = 0; r.reward = 0.0f; r.reward64 = 0.0;
-  bool stepped = false;
-  if (!active) {
-#pragma unroll
-    for (int j = 0; j < RDV_OBS_DIM; ++j) sink(j, 0.0f);
-  } else {
-    Derived d;
-    if (e.flags & FLAG_HALTED) {
-      observation_to(P, e, sink);
-      r.done = 1;
-      if (kDiag && A.diag) { derive<false>(P, e, d); diagnostics(P, e, d, A.diag + i * RDV_DIAG_DIM); }
-    } else {
-      step_env<ST, !kDiag, kGeneral, kRaw>(P, e, a, r, d, sink);
-      stepped = true;
-      if (kDiag) {   // evaluator build only: keeps the training kernel short
-        double dg[RDV_DIAG_DIM];
-        diagnostics(P, e, d, dg);
-        if (A.diag) {
-#pragma unroll
-          for (int j = 0; j < RDV_DIAG_DIM; ++j) A.diag[i * RDV_DIAG_DIM + j] = dg[j];
-        }
-        if (A.eval) eval_accumulate(P, e, d, dg, r.reward64, false, A.eval + i * kEvalDim);
-      }
-    }
-  }
-  return stepped;
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Fused variant: every wave does everything for its 64 envs (step, statistics, divergent in-lane reset, stores).
@@ -489,20 +181,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
     const uint64_t slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;   // (a padding workgroup of the XCD order has no envs)
     float a[RDV_ACT_DIM];
     load_actions(A.actions + wave_base * RDV_ACT_DIM, 0, lane, active, a);
+#ifdef RDV_STAMPS
+    asm volatile("" : : "v"(e.rc[0]), "v"(e.vc[1]), "v"(e.wc[2]), "v"(e.qc[0]), "v"(e.qt[0]), "v"(e.ep_ret), "v"(e.wt[2]), "v"(a[5]));   // (the stamped build waits for the inputs here)
+    RDV_STAMP(1);
+#endif
     StepResult r;
     const RowSink my_row{wl + lane * RDV_OBS_DIM};      // the observation is staged as it is formed
-    const bool stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row);
+    V packed[kChunks];
+    const bool stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row, NoHook(), packed);
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
     store_step_outputs<true>(Aw, lane, active, fin, r, e, my_row.row);
     const bool to_reset = fin && resets;
-    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
+    if (fin && A.on_done == RDV_ON_DONE_HALT) { e.flags |= FLAG_HALTED; packed[5].z = u2s(e.flags, ST(0)); }
     if (resets) {
       job_kind[threadIdx.x] = to_reset ? JOB_REFILL : JOB_NONE;
       job_counter[threadIdx.x] = e.episode;
     }
-    if (stepped && !to_reset) store_env<ST>(wsw, A.cs, lane, e, false);   // a listed env's state is written by the parts, all seven chunks
+    if (stepped && !to_reset) store_chunks<ST>(wsw, A.cs, lane, packed, false);   // a listed env's state is written by the parts, all seven chunks
   }
   RDV_STAMP(3);
   if (resets) {
@@ -613,7 +310,8 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     // one is stored (one wave per SIMD here: the 17 registers cost no occupancy).
     float obs_r[RDV_OBS_DIM];
     float* my_row = wl + lane * RDV_OBS_DIM;
-    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; });
+    V packed[kChunks];
+    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; }, NoHook(), packed);
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     const bool to_reset = fin && resets;
@@ -625,8 +323,8 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     // The state of the envs that go on is stored BEFORE the barrier (round 3): the step waves reach it ~700 cycles ahead of the service
     // waves, and these 6 x 16-byte-per-lane stores drain inside that wait instead of after it (tools/lib_ab.py: 6.80 -> 6.73 us at
     // 65,536 envs, 5.35 -> 5.29 at 16,384; moving the reward / done / terminal-row stores there as well loses: 6.89).  Reset lanes: service wave.
-    if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
-    if (stepped && !to_reset) store_env<ST>(ws, A.cs, i, e, false);
+    if (fin && A.on_done == RDV_ON_DONE_HALT) { e.flags |= FLAG_HALTED; packed[5].z = u2s(e.flags, ST(0)); }
+    if (stepped && !to_reset) store_chunks<ST>(ws, A.cs, i, packed, false);
     RDV_STAMP(3);
     __syncthreads();
     RDV_STAMP(4);
@@ -923,6 +621,8 @@ static void derive_params(const RdvParams& p, DevParams& d) {
   }
   d.rc0_range = p.rc0_range; d.vc0_range = p.vc0_range; d.qc0_range = p.qc0_range;
   d.wc0_range = p.wc0_range; d.qt0_range = p.qt0_range; d.wt0_range = p.wt0_range;
+  d.qc0_tiny = (0.25 * p.qc0_range * p.qc0_range <= kTinyU) ? 1 : 0;   // theta = range * u, 0 < u < 1 (deviate)
+  d.qt0_tiny = (0.25 * p.qt0_range * p.qt0_range <= kTinyU) ? 1 : 0;
 }
 
 struct DeviceGuard {
@@ -955,6 +655,8 @@ struct RdvEnvBatch {
   int variant;       // RdvKernelVariant
   int64_t cs;        // chunk stride in envs (chunk_stride)
   int xcd_order;     // fused kernels' block order: -1 by size (xcd_order_by_size), 0 plain, 1 XCD-contiguous
+  int tiles_grid;    // RDV_VARIANT_FUSED_TILES: grid in workgroups (0: kTilesPerCU per CU; RDV_TILES_GRID in the environment, diagnostics)
+  int n_cus;         // compute units of the device
   RdvRigidBody body; // rdv_set_rigid_body
   bool general;      // step with the RK45 kernels (body is not isotropic / torque-free, or RK45 was asked for)
   bool raw_state;    // rdv_set_state since the last step: quaternions may be unnormalised (next step: kRaw kernel)
@@ -1302,6 +1004,8 @@ int rdv_create(const RdvParams* params, int64_t n_envs, int device, int storage,
   h->n = n_envs; h->cs = chunk_stride(n_envs, storage); h->device = device; h->storage = storage; h->on_done = on_done; h->seed = seed; h->env_id_offset = env_id_offset;
   h->tape = nullptr; h->tape_depth = 0; h->fresh = true; h->variant = RDV_VARIANT_AUTO;
   { const char* x = getenv("RDV_XCD_ORDER"); h->xcd_order = (x && (x[0] == '0' || x[0] == '1') && !x[1]) ? x[0] - '0' : -1; }
+  { const char* x = getenv("RDV_TILES_GRID"); const long v = x ? atol(x) : 0; h->tiles_grid = v > 0 && v <= 65536 ? (int)(v + 7) / 8 * 8 : 0; }
+  { int cus = 0; h->n_cus = (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ? cus : 256; }
   const int64_t bytes = rdv_workspace_bytes(n_envs, storage);
   if (workspace) { h->ws = workspace; h->own_ws = false; }
   else {
@@ -1469,7 +1173,8 @@ int rdv_debug_set_stamps(rdv_handle h, unsigned long long* stamps) {   // diagno
 #endif
 int rdv_set_kernel_variant(rdv_handle h, int variant) {
   RDV_CHECK_HANDLE(h);
-  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT && variant != RDV_VARIANT_FUSED_INLANE)
+  if (variant != RDV_VARIANT_AUTO && variant != RDV_VARIANT_FUSED && variant != RDV_VARIANT_SPLIT && variant != RDV_VARIANT_FUSED_INLANE &&
+      variant != RDV_VARIANT_FUSED_TILES)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_kernel_variant: bad variant %d", variant);
   h->variant = variant;
   return RDV_OK;
@@ -1544,7 +1249,17 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true, false, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false, false, true>), grid, block); }
       else { if (dg) RDV_LAUNCH((step_kernel<double, true, false, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false, false, true>), grid, block); }
     } else if (!dg && h->variant != RDV_VARIANT_FUSED_INLANE) {
-      if (f32) RDV_LAUNCH(step_kernel_parts<float>, grid, block); else RDV_LAUNCH(step_kernel_parts<double>, grid, block);
+      const bool tiles = h->variant == RDV_VARIANT_FUSED_TILES && h->on_done != RDV_ON_DONE_HALT && h->tape_depth == 0;   // (halted envs skip the transition, a reset tape is a test device: step_kernel_parts)
+      if (tiles) {
+        // the tile loop: a grid of kTilesPerCU workgroups per CU (a multiple of 8: one eighth per XCD), never more than there are tiles
+        unsigned g = h->tiles_grid ? (unsigned)h->tiles_grid : (unsigned)(h->n_cus * kTilesPerCU + 7) / 8u * 8u;
+        const unsigned need = A.xcd_per ? (unsigned)A.xcd_per * 8u : grid.x;
+        if (g > need) g = need;
+        grid = dim3(g);
+        launch_step_tiles(f32, grid, s, h->dev_params, A);
+      } else {
+        if (f32) RDV_LAUNCH(step_kernel_parts<float>, grid, block); else RDV_LAUNCH(step_kernel_parts<double>, grid, block);
+      }
     } else {
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false>), grid, block); }
       else { if (dg) RDV_LAUNCH((step_kernel<double, true>), grid, block); else RDV_LAUNCH((step_kernel<double, false>), grid, block); }

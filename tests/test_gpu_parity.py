@@ -31,7 +31,7 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
-@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane", "fused_tiles"])
 @pytest.mark.parametrize("name", SCENARIOS)
 def test_golden_transitions_fp64_storage(name, variant):
     """HIP kernel (parity mode) vs the reference's own recorded transitions."""
@@ -77,7 +77,7 @@ def test_golden_transitions_fp64_storage(name, variant):
     env.close()
 
 
-@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane", "fused_tiles"])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
 @pytest.mark.parametrize("name", ["A_random", "C_variant", "D_stochastic"])
 def test_golden_actions_vs_oracle(name, storage, variant):
@@ -121,7 +121,7 @@ def _compare_run(env, orc, action_list, storage, check_every=1):
         assert abs(sg[k] - so[k]) <= 1e-5 * max(1.0, abs(so[k])), (k, sg[k], so[k])
 
 
-@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane", "fused_tiles"])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
 def test_config2_4096x512_random_actions_philox_resets(storage, variant):
     """BASELINE config 2: 4096 envs x 512 steps, U(-1,1) actions keyed by (seed, step, env), in-kernel Philox resets."""
@@ -134,7 +134,7 @@ def test_config2_4096x512_random_actions_philox_resets(storage, variant):
     assert env.get_stats()["episodes"] > 50_000     # ~5 % of envs end per step (bubble)
 
 
-@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane", "fused_tiles"])
 def test_ragged_sizes_and_masked_reset(variant):
     """N not a multiple of the wave / block size, single env, and reset(mask)."""
     for n in (1, 63, 65, 129, 257, 1000):

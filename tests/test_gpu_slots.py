@@ -62,7 +62,7 @@ CASES = [
 
 @pytest.mark.parametrize("case", CASES, ids=lambda c: f"n{c['n']}-{c['storage']}-{'-'.join(c['kw']) or 'default'}")
 def test_step_layouts_and_persistent_kernels_agree(case):
-    """rdv_step in its three layouts, rdv_step_many and rdv_rollout's env phase (driven through step_many's tape here) on parameter
+    """rdv_step in its four layouts (the tile loop also with a grid of 8 workgroups in a child test below: many tiles per workgroup), rdv_step_many and rdv_rollout's env phase (driven through step_many's tape here) on parameter
     sets that reset often, every step, or into states whose collided / success flags are set at reset: observations, rewards,
     dones, reasons, terminal observations, episode returns / lengths, state, bookkeeping, statistics."""
     n, storage, T = case["n"], case["storage"], 60
@@ -70,10 +70,12 @@ def test_step_layouts_and_persistent_kernels_agree(case):
     ref = _batch(n, params=p, storage=storage, seed=21, variant="fused")
     other = _batch(n, params=p, storage=storage, seed=21, variant="split")
     inlane = _batch(n, params=p, storage=storage, seed=21, variant="fused_inlane")
+    tiles = _batch(n, params=p, storage=storage, seed=21, variant="fused_tiles")
     many = _batch(n - n % 4, params=p, storage=storage, seed=21)
     o0 = ref.reset().clone()
     _same(o0, other.reset(), "split: reset obs")
     _same(o0, inlane.reset(), "in-lane: reset obs")
+    _same(o0, tiles.reset(), "tile loop: reset obs")
     _same(o0[: n - n % 4], many.reset(), "step_many: reset obs")
     acts = [torch.from_numpy(counter_actions(4, t, n)).cuda() for t in range(T)]
     n_done = 0
@@ -87,8 +89,10 @@ def test_step_layouts_and_persistent_kernels_agree(case):
         _assert_same_step(want, _step_outputs(other), t, "split")
         inlane.step(acts[t])
         _assert_same_step(want, _step_outputs(inlane), t, "in-lane")
+        tiles.step(acts[t])
+        _assert_same_step(want, _step_outputs(tiles), t, "tile loop")
     assert n_done > n // 2
-    for name, b in (("split", other), ("in-lane", inlane)):
+    for name, b in (("split", other), ("in-lane", inlane), ("tile loop", tiles)):
         _same(ref.get_state(), b.get_state(), f"{name}: state")
         _same(ref.get_aux(), b.get_aux(), f"{name}: aux")
         assert ref.get_stats() == b.get_stats(), name
@@ -107,10 +111,10 @@ def test_step_layouts_and_persistent_kernels_agree(case):
                     _same(out[k_][j], outs[t + j][key][:m], f"step_many: {k_}, step {t + j}")
         t += K
     _same(ref.get_state()[:m], many.get_state(), "step_many: state")
-    ref.close(); other.close(); inlane.close(); many.close()
+    ref.close(); other.close(); inlane.close(); tiles.close(); many.close()
 
 
-@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane", "fused_tiles"])
 @pytest.mark.parametrize("storage", ["f32", "f64"])
 def test_training_kernels_vs_oracle_with_philox_resets(storage, variant):
     """The training kernels themselves (no diagnostics) against the CPU oracle: config-2 shape, shortened; plus parameters
@@ -139,7 +143,7 @@ def test_training_kernels_vs_oracle_with_philox_resets(storage, variant):
         env.close()
 
 
-@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane"])
+@pytest.mark.parametrize("variant", ["fused", "split", "fused_inlane", "fused_tiles"])
 def test_training_kernels_replay_the_reference_tape(variant):
     """Reset tape (the initial states the unmodified reference drew) through the training kernels (no diagnostics)."""
     g = load_golden("steps_A_random.npz")
@@ -303,3 +307,37 @@ def test_xcd_contiguous_block_order_gives_the_same_results(monkeypatch):
         b.close()
     assert ref.get_stats()["episodes"] > n
     ref.close()
+
+
+def test_tile_loop_walks_many_tiles_per_workgroup(monkeypatch):
+    """RDV_VARIANT_FUSED_TILES with a grid far smaller than the number of tiles (RDV_TILES_GRID: 8 and 16 workgroups for 41 tiles of 256
+    envs, so every workgroup runs its look-ahead loop five or three times; ragged batch, both block orders, fp32 and fp64 storage):
+    bit for bit the one-tile-per-workgroup kernel."""
+    n, T = 40 * 256 + 130, 48
+    p = make_params(t_max=9.0)
+    for storage in ("f32", "f64"):
+        ref = _batch(n, params=p, storage=storage, seed=13, variant="fused")
+        others = []
+        for grid, order in (("8", "0"), ("8", "1"), ("16", "1")):
+            monkeypatch.setenv("RDV_TILES_GRID", grid)
+            monkeypatch.setenv("RDV_XCD_ORDER", order)
+            others.append(_batch(n, params=p, storage=storage, seed=13, variant="fused_tiles"))
+        monkeypatch.delenv("RDV_TILES_GRID")
+        monkeypatch.delenv("RDV_XCD_ORDER")
+        o0 = ref.reset().clone()
+        for b in others:
+            _same(o0, b.reset(), "reset obs")
+        for t in range(T):
+            a = torch.from_numpy(counter_actions(9, t, n)).cuda()
+            ref.step(a)
+            want = _step_outputs(ref)
+            for k, b in enumerate(others):
+                b.step(a)
+                _assert_same_step(want, _step_outputs(b), t, f"tile loop {k} ({storage})")
+        for b in others:
+            _same(ref.get_state(), b.get_state(), "state")
+            _same(ref.get_aux(), b.get_aux(), "aux")
+            assert ref.get_stats() == b.get_stats()
+            b.close()
+        assert ref.get_stats()["episodes"] > n
+        ref.close()

@@ -13,9 +13,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SRC = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_hip.hip")
-BASE = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-mllvm",
-        "-amdgpu-kernarg-preload-count=16", "-shared"]
+from _build import build_variant   # (tools/ is sys.path[0])
 
 
 def child(args):
@@ -90,7 +88,7 @@ def main():
     for spec in args.specs:
         name, _, flags = spec.partition(":")
         lib = os.path.join(ROOT, "tools", f"_ab_{name}.so")
-        subprocess.check_call(BASE + [f for f in flags.split(",") if f] + ["-o", lib, SRC])
+        build_variant(lib, [f for f in flags.split(",") if f])
         libs.append((name, lib))
         print(f"built {name} [{flags}]", flush=True)
     res = {name: [] for name, _ in libs}

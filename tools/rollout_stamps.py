@@ -13,9 +13,8 @@ sys.path.insert(0, ROOT)
 def main():
     n, T = 65536, 64
     lib = os.path.join(ROOT, "tools", "_stamps.so")
-    src = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_hip.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16",
-                           "-DRDV_STAMPS", "-shared", "-o", lib, src])
+    from _build import build_variant
+    build_variant(lib, ["-DRDV_STAMPS"])
     import torch
     from reinforcement_learning_rendezvous_amd import _native
     _native.LIB_PATH = lib

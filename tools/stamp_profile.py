@@ -23,9 +23,8 @@ def main():
     svc = 1          # service waves per step wave (round 3 also stamped a 12-wave workgroup with two: profiles/r03_split_service_waves_stamps.txt)
     wpg = 4 * (1 + svc)
     lib = os.path.join(ROOT, "tools", "_stamps.so")
-    src = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_hip.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DRDV_STAMPS"] + os.environ.get("RDV_EXTRA_FLAGS", "").split() +
-                          ["-shared", "-o", lib, src])
+    from _build import build_variant
+    build_variant(lib, ["-DRDV_STAMPS"] + os.environ.get("RDV_EXTRA_FLAGS", "").split())
     import torch
     from reinforcement_learning_rendezvous_amd import _native
     _native.LIB_PATH = lib

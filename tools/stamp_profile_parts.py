@@ -22,14 +22,13 @@ sys.path.insert(0, ROOT)
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4194304
     lib = os.path.join(ROOT, "tools", "_stamps.so")
-    src = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc", "rdv_hip.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-mllvm", "-amdgpu-kernarg-preload-count=16", "-DRDV_STAMPS"] +
-                          os.environ.get("RDV_EXTRA_FLAGS", "").split() + ["-shared", "-o", lib, src])
+    from _build import build_variant
+    build_variant(lib, ["-DRDV_STAMPS"] + os.environ.get("RDV_EXTRA_FLAGS", "").split())
     import torch
     from reinforcement_learning_rendezvous_amd import _native
     _native.LIB_PATH = lib
     from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
-    env = RendezvousBatch(n, device="cuda:0", storage="f32", seed=0)
+    env = RendezvousBatch(n, device="cuda:0", storage="f32", seed=0, variant="fused")
     L = _native.lib()
     L.rdv_debug_set_stamps.argtypes = [C.c_void_p, C.c_void_p]
     waves = ((n + 255) // 256 + 8) * 4

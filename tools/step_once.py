@@ -7,6 +7,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
+from reinforcement_learning_rendezvous_amd import _native
+if os.environ.get("RDV_LIB"):          # another build of the library (A/B of counters)
+    _native.LIB_PATH = os.environ["RDV_LIB"]
+    _native.STRICT = False
 from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
