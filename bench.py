@@ -106,6 +106,20 @@ def cpu_baseline(n, seconds):
                                                 "cannot travel to the GPU box, so this figure is quoted from BASELINE.md section 2, not measured in this run"}}
 
 
+def rank_environment(env):
+    """Environment every rank of a multi-process run needs BEFORE it imports torch / touches HIP, as additions to `env` (existing
+    values win).  HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports dmabuf IPC only; without it RCCL's (and PyTorch's)
+    cross-process sharing of device memory fails in hipIpcGetMemHandle ("invalid argument") — stated by the environment's own notes,
+    exported on the build container and the GPU boxes; set here as well so that a rank started by ANY launcher (the driver's
+    `python -m torch.distributed.run ... bench.py`, not only this file's own spawn path) cannot come up without it."""
+    add = {}
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in env:
+        add["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if "OMP_NUM_THREADS" not in env:
+        add["OMP_NUM_THREADS"] = "1"
+    return add
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD `python -m torch.distributed.run` (this process
     has made no GPU call — torch is not even imported yet — and never replaces itself), pass its stderr through, relay rank 0's
@@ -119,8 +133,7 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("OMP_NUM_THREADS", "1")
+    env.update(rank_environment(env))     # what every rank needs, whoever starts it: main() applies the same to launcher-started ranks
     print("[bench] starting " + " ".join(cmd[1:7]) + " ...", file=sys.stderr, flush=True)
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     lines = 0
@@ -147,6 +160,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    if under_launcher:
+        os.environ.update(rank_environment(os.environ))     # before torch is imported: the HIP runtime reads it at initialisation
     import torch
     import torch.distributed as dist
     from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
@@ -251,6 +266,18 @@ def main():
         per_rank_us = [float(x) / K * 1e6 for x in table.cpu()]
         elapsed = float(table.max().item())            # the MAX over ranks is what the job took
     launch_us = elapsed / K * 1e6
+    # who ran: every rank's device, so that the record shows `world` DISTINCT GPUs (name, PCI bus id, HIP device index, host pid)
+    props = torch.cuda.get_device_properties(device)
+    pci = "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0))
+    me = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "device_name": props.name, "pci_bus_id": pci,
+          "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid(),
+          "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    devices = [me]
+    rccl_world = None
+    if distributed:
+        devices = [None] * world
+        dist.all_gather_object(devices, me)                 # (a few hundred bytes, once, outside every timed region)
+        rccl_world = dist.get_world_size()
     stats = env.get_stats()
     assert stats["env_steps"] == n * K * R, (stats["env_steps"], n * K * R)   # exactly R x K launches over n envs were executed
     global_stats = stats
@@ -362,7 +389,10 @@ def main():
                                  "fraction is notional at this size; large_n below is the same metric beyond that cache"},
             "episodes_finished": global_stats["episodes"],
             "per_rank": {"launch_us": per_rank_us, "max_over_ranks_us": launch_us, "backend": args.backend if distributed else None,
-                         "process_group": bool(distributed)},
+                         "process_group": bool(distributed), "devices": devices,
+                         "distinct_devices": len({(d["pci_bus_id"], d["uuid"]) for d in devices})},
+            "rccl_world": rccl_world if (distributed and args.backend == "nccl") else None,
+            "process_group_world": rccl_world,
         }
         if gather_info is not None:
             out.update(gather_info)
@@ -428,11 +458,13 @@ def main():
                                         "ms_per_step": {"mean": sum(per) / len(per) * 1e3, "median": order[len(per) // 2] * 1e3,
                                                         "p90": order[int(len(per) * 0.9)] * 1e3, "p99": order[int(len(per) * 0.99)] * 1e3,
                                                         "max": order[-1] * 1e3},
-                                        "phases_ms": {"names": ["step kernel + the message's D2H (synchronises)", "done mask", "finished rows picked on the host", "infos dicts"],
-                                                      "median_step": [sorted(p_[j] for p_ in phases)[len(phases) // 2] * 1e3 for j in range(4)],
-                                                      "slowest_step": [x_ * 1e3 for x_ in phases[worst][:4]]},
-                                        "finished_envs_per_step": {"median": sorted(p_[4] for p_ in phases)[len(phases) // 2],
-                                                                   "max": max(p_[4] for p_ in phases), "in_the_slowest_step": phases[worst][4]},
+                                        "phases_ms": {"names": ["step kernel + the message's D2H (synchronises)", "done mask + output views (copies)",
+                                                                "last step's finished entries re-pointed at the shared empty dict + flatnonzero",
+                                                                "finished rows picked on the host", "infos dicts of the finished envs"],
+                                                      "median_step": [sorted(p_[j] for p_ in phases)[len(phases) // 2] * 1e3 for j in range(5)],
+                                                      "slowest_step": [x_ * 1e3 for x_ in phases[worst][:5]]},
+                                        "finished_envs_per_step": {"median": sorted(p_[5] for p_ in phases)[len(phases) // 2],
+                                                                   "max": max(p_[5] for p_ in phases), "in_the_slowest_step": phases[worst][5]},
                                         "gc": {"collections_by_generation": [sum(1 for g_, _, _ in pauses if g_ == j) for j in range(3)],
                                                "longest_pause_ms": max([d_ for _, d_, _ in pauses], default=0.0) * 1e3,
                                                "gc_ms_inside_the_slowest_step": gc_in_step[worst] * 1e3,

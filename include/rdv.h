@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define RDV_ABI_VERSION 3
+#define RDV_ABI_VERSION 4
 #define RDV_OBS_DIM 17    /* rendezvous_env.py:133-137 */
 #define RDV_ACT_DIM 6     /* rendezvous_env.py:140-144 */
 #define RDV_STATE_DIM 20  /* rc3 vc3 qc4 wc3 qt4 wt3, the column order of results/data_monte_carlo_initial_conditions.csv */
@@ -45,7 +45,11 @@ typedef enum RdvError {
   RDV_ERR_BAD_HANDLE = -5,
   RDV_ERR_BAD_PARAMS = -6,     /* violates an assert of the reference ctor (rendezvous_env.py:148-156) */
   RDV_ERR_DEVICE_FAULT = -7    /* a kernel of this handle reported a fault in its device error word (RdvDeviceError); the handle's
-                                  results since then are not to be trusted.  Sticky: every later call on the handle returns it too */
+                                  results since then are not to be trusted.  Sticky: once a synchronising call (below) has read the
+                                  word, every call that launches work on the handle or reads its state returns this code — rdv_reset,
+                                  rdv_step, rdv_step_many, rdv_rollout, rdv_set_state, rdv_get_state, rdv_get_aux, rdv_observe,
+                                  rdv_diagnose, rdv_snapshot, rdv_restore, rdv_eval_begin, rdv_eval_summary, rdv_get_stats; the
+                                  parameter setters and rdv_destroy still work */
 } RdvError;
 
 /* Bits of a handle's device error word: written by the kernels (atomic OR into a word of the workspace), read back by the calls
@@ -167,6 +171,10 @@ const char* rdv_last_error(void);
 /* The RdvError a device error word stands for (RDV_OK for 0, RDV_ERR_DEVICE_FAULT otherwise) with the message rdv_last_error()
  * then returns naming every bit that is set.  Host-only, needs no GPU: it is the check rdv_get_stats applies to the word it reads. */
 int         rdv_device_error_code(uint32_t device_error_word);
+/* Test hook (ABI 4): ORs `bits` into the handle's device error word ON THE DEVICE, ordered on `stream` — exactly what a kernel that
+ * detects a fault does — so that the host side of the contract (which calls read the word, which refuse afterwards) can be exercised
+ * on hardware without provoking a real fault. */
+int         rdv_debug_set_device_error(rdv_handle h, uint32_t bits, void* stream);
 
 /* Reference ctor defaults (rendezvous_env.py:52-126, :313). Host-only, needs no GPU. */
 int rdv_params_default(RdvParams* out_host);

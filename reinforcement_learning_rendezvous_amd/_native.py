@@ -23,7 +23,7 @@ ERROR_NAMES = {0: "RDV_OK", -1: "RDV_ERR_INVALID_ARGUMENT", -2: "RDV_ERR_NO_DEVI
 DEVERR_LOST_SIGNAL = 1
 
 # every symbol include/rdv.h declares (tests/test_abi.py checks the list against the header and the .so)
-SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_device_error_code", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
+SYMBOLS = ["rdv_version", "rdv_last_error", "rdv_device_error_code", "rdv_debug_set_device_error", "rdv_params_default", "rdv_params_validate", "rdv_workspace_bytes",
            "rdv_create", "rdv_destroy", "rdv_set_params", "rdv_get_params", "rdv_seed", "rdv_set_reset_tape",
            "rdv_set_kernel_variant", "rdv_rigid_body_default", "rdv_set_rigid_body", "rdv_get_rigid_body",
            "rdv_reset", "rdv_step", "rdv_step_many", "rdv_set_state", "rdv_get_state", "rdv_get_aux", "rdv_snapshot_bytes", "rdv_snapshot", "rdv_restore", "rdv_observe", "rdv_diagnose",
@@ -107,6 +107,7 @@ def lib():
         "rdv_version": (C.c_int, []),
         "rdv_last_error": (C.c_char_p, []),
         "rdv_device_error_code": (C.c_int, [C.c_uint32]),
+        "rdv_debug_set_device_error": (C.c_int, [vp, C.c_uint32, vp]),
         "rdv_params_default": (C.c_int, [PP]),
         "rdv_params_validate": (C.c_int, [PP]),
         "rdv_workspace_bytes": (i64, [i64, C.c_int]),
@@ -146,7 +147,7 @@ def lib():
         fn = getattr(L, name, None)
         if fn is None:
             if STRICT:
-                raise RdvError(-2, f"{LIB_PATH} does not export {name}: it is not a build of this source tree (ABI {SYMBOLS and 3})")
+                raise RdvError(-2, f"{LIB_PATH} does not export {name}: it is not a build of this source tree (ABI 4)")
             continue
         fn.restype, fn.argtypes = res, args
     _lib = L

@@ -99,10 +99,21 @@ class RendezvousBatch:
     # obs / reward / done: the batch's current observation, last rewards and dones.  rdv_step writes them; the persistent launches
     # (step_many, rollout) write their own [K,N,...] buffers instead, and the last rows are copied over only when somebody asks —
     # a timed loop of persistent launches carries no extra copy kernels.
+    # The views are copied ON THE STREAM OF THE LAUNCH that wrote them (the current stream then waits for that copy), so a reader on
+    # another stream cannot overtake the launch.  The caller's side of the contract: the ``out`` buffers of that launch are not
+    # overwritten — by another batch's rollout, a reused gather message — before this batch's next call or first read of obs /
+    # reward / done; they are what ``obs`` IS until then.
     def _sync(self):
-        src, self._pending = self._pending, None
-        for name, t in src.items():
-            getattr(self, "_" + name).copy_(t)
+        (src, stream), self._pending = self._pending, None
+        cur = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(stream):
+            for name, t in src.items():
+                getattr(self, "_" + name).copy_(t)
+        if stream != cur:
+            cur.wait_stream(stream)
+
+    def _defer(self, **views):
+        self._pending = (views, torch.cuda.current_stream(self.device))
 
     @property
     def obs(self):
@@ -215,7 +226,7 @@ class RendezvousBatch:
         so = N.StepOut(out["obs"].data_ptr(), out["reward"].data_ptr(), out["done"].data_ptr(), None, None, None,
                        out["done_reason"].data_ptr(), None, None)
         N.check(self._lib.rdv_step_many(self._h, actions.data_ptr(), K, C.byref(so), self._stream()))
-        self._pending = dict(obs=out["obs"][K - 1], reward=out["reward"][K - 1], done=out["done"][K - 1])   # copied on first access
+        self._defer(obs=out["obs"][K - 1], reward=out["reward"][K - 1], done=out["done"][K - 1])   # copied on first access
         return out
 
     def act(self, policy, deterministic=False, out=None):
@@ -244,7 +255,7 @@ class RendezvousBatch:
                                       C.c_uint64(policy.noise_seed), C.c_uint64(policy._calls), self._stream()))
         policy._calls += T
         # the batch's current observation / last rewards / dones, as after step(): copied on first access
-        self._pending = dict(obs=out["last_obs"], reward=out["reward"][T - 1], done=out["done"][T - 1])
+        self._defer(obs=out["last_obs"], reward=out["reward"][T - 1], done=out["done"][T - 1])
         return out
 
     # ------------------------------------------------------------------------------------------------ evaluator helpers
@@ -289,7 +300,8 @@ class RendezvousBatch:
         snap = snap.contiguous()
         N.check(self._lib.rdv_restore(self._h, snap.data_ptr(), snap.numel(), self._stream()))
         self._fresh = False
-        self.obs.copy_(self.observe())
+        self._pending = None          # the last rows of an earlier persistent launch are not this state's observation
+        self._obs.copy_(self.observe())
 
     def clone(self):
         """An independent batch in the same state — what ``copy.deepcopy(env)`` gives the reference (utils/environment_utils.py:66-73;
@@ -372,6 +384,11 @@ class RendezvousBatch:
         return dict(inertia=np.array(b.inertia_chaser).reshape(3, 3), inertia_target=np.array(b.inertia_target).reshape(3, 3),
                     torque=np.array(b.torque_chaser), torque_target=np.array(b.torque_target), rtol=b.rtol, atol=b.atol,
                     integrator={v: k for k, v in N.INTEGRATORS.items()}[b.integrator])
+
+    def set_kernel_variant(self, variant):
+        """Change the step kernel layout (``__init__``'s ``variant``); results do not depend on it.  ``clone()`` carries it over."""
+        N.check(self._lib.rdv_set_kernel_variant(self._h, _VARIANT[variant]))
+        self._ctor["variant"] = variant
 
     def set_reward_kwargs(self, **kw):
         """The reference passes these to get_bubble_reward on every step (rendezvous_env.py:211, :313)."""

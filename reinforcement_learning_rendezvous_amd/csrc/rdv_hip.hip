@@ -491,6 +491,10 @@ __global__ __launch_bounds__(kWave) void params_kernel(const DevParams src, DevP
   uint32_t* to = reinterpret_cast<uint32_t*>(dst);
   for (int k = threadIdx.x; k < (int)(sizeof(DevParams) / 4); k += kWave) to[k] = from[k];
 }
+// rdv_debug_set_device_error: what a kernel that detects a fault does to the handle's error word
+__global__ __launch_bounds__(kWave) void device_error_kernel(uint32_t* word, uint32_t bits) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_or(word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 static_assert(sizeof(DevParams) % 4 == 0 && sizeof(DevParams) <= 3072, "DevParams is passed by value to params_kernel");
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -723,6 +727,14 @@ int rdv_device_error_code(uint32_t word) {
   if (word & RDV_DEVERR_LOST_SIGNAL) std::strncat(what, " LOST_SIGNAL (rdv_rollout: an env wave's bounded wait for its workgroup's slot-refill signal expired)", sizeof what - std::strlen(what) - 1);
   if (word & ~(uint32_t)RDV_DEVERR_LOST_SIGNAL) std::strncat(what, " unknown bits", sizeof what - std::strlen(what) - 1);
   return fail(RDV_ERR_DEVICE_FAULT, "device error word 0x%x:%s; results of this handle since the fault are not to be trusted", word, what);
+}
+
+int rdv_debug_set_device_error(rdv_handle h, uint32_t bits, void* stream) {
+  RDV_CHECK_HANDLE(h);
+  DeviceGuard guard(h->device);
+  hipLaunchKernelGGL(device_error_kernel, dim3(1), dim3(kWave), 0, static_cast<hipStream_t>(stream), h->dev_error, bits);
+  RDV_HIP(hipGetLastError());
+  return RDV_OK;
 }
 
 int rdv_params_default(RdvParams* p) {
@@ -1189,6 +1201,7 @@ int rdv_set_reset_tape(rdv_handle h, const double* tape, int32_t depth) {
 
 int rdv_reset(rdv_handle h, const uint8_t* mask, float* obs_out, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   DeviceGuard guard(h->device);
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int fresh = (h->fresh && !mask) ? 1 : 0;
@@ -1328,6 +1341,7 @@ static int access(rdv_handle h, int what, const double* in, double* out, float* 
 
 int rdv_set_state(rdv_handle h, const double* states, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   if (!states) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_state: null states");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_set_state: call rdv_reset first (monte_carlo.py:106 resets before overwriting the state)");
   h->raw_state = true;
@@ -1335,6 +1349,7 @@ int rdv_set_state(rdv_handle h, const double* states, void* stream) {
 }
 int rdv_get_state(rdv_handle h, double* out, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_state: null output");
   return access(h, ACC_GET_STATE, nullptr, out, nullptr, stream);
 }
@@ -1358,6 +1373,7 @@ int64_t rdv_snapshot_bytes(rdv_handle h) {
 }
 int rdv_snapshot(rdv_handle h, void* dst, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   if (!dst) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_snapshot: null destination");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_snapshot: nothing to save before the first rdv_reset");
   DeviceGuard guard(h->device);
@@ -1378,7 +1394,10 @@ int rdv_restore(rdv_handle h, const void* src, int64_t src_bytes, void* stream) 
   hipStream_t s = static_cast<hipStream_t>(stream);
   SnapshotHeader hd;   // the header is validated on the host: this call synchronises `stream`
   RDV_HIP(hipMemcpyAsync(&hd, src, sizeof hd, hipMemcpyDeviceToHost, s));
+  RDV_HIP(hipMemcpyAsync(&h->host_error_word, h->dev_error, sizeof(uint32_t), hipMemcpyDeviceToHost, s));   // (it synchronises anyway)
   RDV_HIP(hipStreamSynchronize(s));
+  h->device_error |= h->host_error_word;
+  RDV_CHECK_FAULT(h);
   if (hd.magic != kSnapMagic || hd.version != 1) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: the buffer does not start with a snapshot header");
   if (hd.n_envs != h->n || hd.storage != h->storage)
     return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_restore: snapshot of %lld envs with storage %d, this batch has %lld envs with storage %d",
@@ -1395,22 +1414,26 @@ int rdv_restore(rdv_handle h, const void* src, int64_t src_bytes, void* stream) 
 
 int rdv_get_aux(rdv_handle h, double* out, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_get_aux: null output");
   return access(h, ACC_GET_AUX, nullptr, out, nullptr, stream);
 }
 int rdv_observe(rdv_handle h, float* out, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_observe: null output");
   return access(h, ACC_OBSERVE, nullptr, nullptr, out, stream);
 }
 int rdv_diagnose(rdv_handle h, double* out, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   if (!out) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_diagnose: null output");
   return access(h, ACC_DIAGNOSE, nullptr, out, nullptr, stream);
 }
 
 int rdv_eval_begin(rdv_handle h, double* eval, void* stream) {
   RDV_CHECK_HANDLE(h);
+  RDV_CHECK_FAULT(h);
   if (!eval) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_eval_begin: null accumulators");
   if (h->fresh) return fail(RDV_ERR_INVALID_ARGUMENT, "rdv_eval_begin: call rdv_reset first");
   return access(h, ACC_EVAL_BEGIN, nullptr, eval, nullptr, stream);

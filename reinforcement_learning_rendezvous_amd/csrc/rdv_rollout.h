@@ -290,6 +290,7 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
 #ifdef RDV_STAMPS
    unsigned long long acc_w1 = 0, acc_tr = 0, acc_tail = 0, acc_w2 = 0;
 #endif
+   bool lost = false;   // wave-uniform: this wave's bounded wait expired once (RDV_DEVERR_LOST_SIGNAL is set): later steps do not wait again
    for (int t = 0; t < T; ++t) {
     ROLL_T(te0);
     __syncthreads();   // actions of step t are in LDS; every listed slot has been refilled
@@ -325,11 +326,15 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
         // (every wave must leave the grid): 2^22 polls of ~200 cycles each (s_sleep 2 = 128 cycles + the LDS load) = ~0.35 s at
         // 2.4 GHz, five orders of magnitude above the expected wait.  Expiry is NOT absorbed: the wave sets RDV_DEVERR_LOST_SIGNAL in
         // the handle's device error word before it goes on (its slots may be stale: results from here on may be wrong), and
-        // rdv_get_stats / rdv_eval_summary and every later call on the handle return RDV_ERR_DEVICE_FAULT.
+        // rdv_get_stats / rdv_eval_summary / rdv_restore read it back, after which every launching call on the handle returns
+        // RDV_ERR_DEVICE_FAULT (include/rdv.h).
+        // A wave whose wait has expired once does not wait again: the fault is recorded, the launch's results are void, and a further
+        // ~0.35 s per remaining step (tens of seconds at T = 64) would only delay the host's reading of the error word.
         int spin = 0;
-        while (__hip_atomic_load(refills_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(kGroupWaves * (t + 1))) {
+        while (!lost && __hip_atomic_load(refills_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < (uint32_t)(kGroupWaves * (t + 1))) {
           if (++spin >= (1 << 22)) {
             if (ln == 0) __hip_atomic_fetch_or(A.dev_error, (uint32_t)RDV_DEVERR_LOST_SIGNAL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lost = true;
             break;
           }
           __builtin_amdgcn_s_sleep(2);

@@ -13,6 +13,8 @@ launch plus a small device -> host copy, ~2.5 x 10^4 steps/s — two orders of m
 the batched path.  Use ``RendezvousVecEnv`` / ``RendezvousBatch`` for throughput; use this to run the reference's single-env scripts
 unchanged.
 """
+import inspect
+
 import numpy as np
 import torch
 
@@ -34,8 +36,9 @@ class RendezvousEnv(_EnvBase):
         """``kwargs`` (and positional ``args``, in the reference's order): the reference constructor's arguments
         (rendezvous_env.py:17-37).  ``storage``: "f64" by default — the reference's own precision, which a single env can afford.
         ``engine``: an already constructed one-env batch (tests inject the CPU-oracle-backed twin)."""
-        names = ["rc0", "vc0", "qc0", "wc0", "qt0", "wt0", "rc0_range", "vc0_range", "qc0_range", "wc0_range", "qt0_range",
-                 "wt0_range", "koz_radius", "corridor_half_angle", "h", "dt", "t_max", "reward_kwargs", "quiet"]   # :17-37
+        # positional order = the reference's (:17-37: ..., wt0_range, reward_kwargs, koz_radius, corridor_half_angle, h, dt, t_max, quiet),
+        # read off make_params, which restates that signature and is checked against it (tests/test_host_logic.py)
+        names = list(inspect.signature(make_params).parameters)
         if len(args) > len(names):
             raise TypeError(f"RendezvousEnv takes at most {len(names)} positional arguments")
         for k, v in zip(names, args):
@@ -43,9 +46,16 @@ class RendezvousEnv(_EnvBase):
                 raise TypeError(f"RendezvousEnv got multiple values for argument '{k}'")
             kwargs[k] = v
         self.quiet = bool(kwargs.pop("quiet", False))
+        # The reference's clock is Python arithmetic on the caller's dt (t = 0; t = round(t + dt, 3), :193, :266): an int dt keeps it an int
+        # ("t =   20" in the episode-end line, :380), a float dt makes it a float ("20.0").  None: the reference's own default, the int 1 (:68).
+        self._t_is_int = kwargs.get("dt") is None or isinstance(kwargs.get("dt"), (int, np.integer))
         if engine is None:
             from .batch import RendezvousBatch
             engine = RendezvousBatch(1, params=make_params(**kwargs), device=device, storage=storage, on_done="continue", seed=seed)
+        else:
+            if kwargs:
+                raise TypeError(f"RendezvousEnv: pass either an engine or the reference constructor's arguments, not both (got {sorted(kwargs)})")
+            self._t_is_int = float(engine.params.dt).is_integer()   # (no caller's dt to look at: whole steps print as integers)
         if engine.num_envs != 1:
             raise ValueError("RendezvousEnv wraps a batch of exactly one env")
         object.__setattr__(self, "batch", engine)
@@ -93,7 +103,7 @@ class RendezvousEnv(_EnvBase):
             s = self._now()[0]
             reason = int(self._h["done_reason"][0]) if self._msg is not None else int(self.batch.done_reason.cpu().numpy()[0])
             t_end = self.t
-            t_end = int(t_end) if float(self.batch.params.dt).is_integer() else t_end
+            t_end = int(round(t_end)) if self._t_is_int else float(t_end)
             print("Episode end | r = " + str(round(float(np.linalg.norm(s[0:3])), 2)).rjust(5) + " | t = " + str(t_end).rjust(4) +
                   " | " + ["", "obs", "time", "bubble", "attitude"][reason & 7].center(8) + " | " + ("Collided" if self.collided else " "))
         info = {"observation": obs, "reward": rew, "done": done, "action": action}   # :214-219
@@ -111,7 +121,9 @@ class RendezvousEnv(_EnvBase):
 
     def __deepcopy__(self, memo):        # copy_env(env) (utils/environment_utils.py:66-73; main.py:83)
         import copy
-        return RendezvousEnv(engine=copy.deepcopy(self.batch, memo), quiet=self.quiet)
+        twin = RendezvousEnv(engine=copy.deepcopy(self.batch, memo), quiet=self.quiet)
+        object.__setattr__(twin, "_t_is_int", self._t_is_int)
+        return twin
 
     # ------------------------------------------------------------------------------------------------ attributes
     def __getattr__(self, name):         # only reached for names that are not ordinary attributes

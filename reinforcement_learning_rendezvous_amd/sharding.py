@@ -199,10 +199,27 @@ def reduce_stats(stats, device=None):
 
 
 def gather_columns(columns, dst=0):
-    """Monte Carlo: per-rank dicts of equally keyed 1-D arrays -> concatenated dict on ``dst`` (rank order)."""
+    """Monte Carlo: per-rank dicts of equally keyed 1-D arrays -> concatenated dict on ``dst`` (rank order).  The columns travel as ONE
+    float64 matrix per rank [n_columns, longest shard] (shards may differ by a row; integer columns are exact up to 2^53) received
+    straight into a preallocated [world, n_columns, longest] buffer on ``dst`` — a plain ``dist.gather`` of tensors like the other
+    collectives of this module, not pickled Python objects."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    gathered = [None] * world if rank == dst else None
-    dist.gather_object({k: np.asarray(v) for k, v in columns.items()}, gathered, dst=dst)
+    device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    keys = list(columns)
+    local = {k: np.asarray(columns[k]) for k in keys}
+    n_local = len(local[keys[0]]) if keys else 0
+    if any(v.ndim != 1 or len(v) != n_local for v in local.values()):
+        raise ValueError("gather_columns: every column must be a 1-D array of this rank's row count")
+    sizes = torch.zeros((world,), dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes, torch.tensor([n_local], dtype=torch.int64, device=device))
+    sizes = [int(x) for x in sizes.cpu()]
+    longest = max(sizes)
+    mine = torch.zeros((len(keys), longest), dtype=torch.float64, device=device)
+    if n_local:
+        mine[:, :n_local] = torch.from_numpy(np.stack([local[k].astype(np.float64) for k in keys])).to(device)
+    table = torch.empty((world, len(keys), longest), dtype=torch.float64, device=device) if rank == dst else None
+    dist.gather(mine, list(table.unbind(0)) if rank == dst else None, dst=dst)
     if rank != dst:
         return None
-    return {k: np.concatenate([g[k] for g in gathered]) for k in columns}
+    t = table.cpu().numpy()
+    return {k: np.concatenate([t[w, j, :sizes[w]] for w in range(world)]).astype(local[k].dtype, copy=False) for j, k in enumerate(keys)}

@@ -28,7 +28,7 @@ def _has_gpu():
 def test_library_is_built_and_loads():
     N.build()
     assert os.path.exists(N.LIB_PATH)
-    assert N.lib().rdv_version() == 3
+    assert N.lib().rdv_version() == 4
 
 
 def test_every_declared_symbol_is_exported():

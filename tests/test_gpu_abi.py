@@ -115,3 +115,71 @@ def test_create_says_which_call_failed():
     ok = _batch(64)                                           # the failure left nothing behind
     ok.reset()
     ok.close()
+
+
+def test_device_fault_is_sticky_on_every_call_the_header_names():
+    """include/rdv.h, RDV_ERR_DEVICE_FAULT: a bit set in the handle's device error word (here by the ABI's test hook, the way a kernel
+    sets it) is invisible until a synchronising call reads it — rdv_get_stats, rdv_eval_summary or rdv_restore, which then return the
+    fault — and from then on every call that launches work on the handle or reads its state refuses with the same code; the parameter
+    setters still work, other handles are unaffected, and the persistent-launch views of a batch follow the stream they were written on."""
+    n = 1024
+    env, other = _batch(n, seed=1), _batch(n, seed=1)
+    a = torch.from_numpy(counter_actions(2, 0, n)).cuda()
+    for b in (env, other):
+        b.reset(); b.step(a)
+    snap = env.snapshot()
+    lib, s = N.lib(), env._stream()
+    assert lib.rdv_debug_set_device_error(env._h, N.DEVERR_LOST_SIGNAL, s) == 0
+    env.step(a)                                           # nothing has read the word yet: launches still go out
+    with pytest.raises(N.RdvError, match="RDV_ERR_DEVICE_FAULT.*LOST_SIGNAL"):
+        env.restore(snap)                                 # a synchronising call: reads the word, refuses
+    calls = [lambda: env.step(a), lambda: env.reset(), lambda: env.get_state(), lambda: env.get_aux(), lambda: env.observe(),
+             lambda: env.diagnose(), lambda: env.snapshot(), lambda: env.restore(snap), lambda: env.set_state(torch.zeros((n, 20), dtype=torch.float64)),
+             lambda: env.eval_begin(), lambda: env.get_stats(), lambda: env.step_many(a[None].contiguous())]
+    for k, f in enumerate(calls):
+        with pytest.raises(N.RdvError, match="RDV_ERR_DEVICE_FAULT"):
+            f()
+    env.set_params(make_params(t_max=30.0))               # setters do not launch env work
+    other.step(a)                                         # another handle is untouched
+    assert other.get_stats()["env_steps"] == 2 * n
+    env.close(); other.close()
+
+    # rdv_get_stats as the first reader
+    env = _batch(n, seed=1)
+    env.reset(); env.step(a)
+    assert lib.rdv_debug_set_device_error(env._h, N.DEVERR_LOST_SIGNAL, env._stream()) == 0
+    with pytest.raises(N.RdvError, match="RDV_ERR_DEVICE_FAULT"):
+        env.get_stats()
+    with pytest.raises(N.RdvError, match="RDV_ERR_DEVICE_FAULT"):
+        env.reset()
+    env.close()
+
+
+def test_pending_rows_of_a_persistent_launch_follow_their_stream():
+    """``batch.obs`` after ``step_many`` / ``rollout`` is a lazily copied view of the launch's last rows: the copy runs on the stream the
+    launch ran on, also when ``obs`` is first read from another stream; ``restore`` drops a stale view; ``clone()`` carries a kernel
+    variant set after construction."""
+    n, K = 4096, 8
+    env, ref = _batch(n, seed=4), _batch(n, seed=4)
+    env.reset(); ref.reset()
+    tape = torch.stack([torch.from_numpy(counter_actions(3, t, n)).cuda() for t in range(K)]).contiguous()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = env.step_many(tape)
+    got = env.obs.clone()                                  # read from the default stream: must wait for the launch on `side`
+    for t in range(K):
+        ref.step(tape[t])
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref.obs) and torch.equal(got, out["obs"][K - 1])
+    snap = ref.snapshot()
+    env.step_many(tape)                                    # leaves a pending view ...
+    env.restore(snap)                                      # ... that is not the restored state's observation
+    assert torch.equal(env.obs, ref.obs)
+    env.set_kernel_variant("fused_inlane")
+    twin = env.clone()
+    assert twin._ctor["variant"] == "fused_inlane"
+    a = tape[0]
+    o1, _, _ = env.step(a); o2, _, _ = twin.step(a)
+    assert torch.equal(o1, o2)
+    env.close(); ref.close(); twin.close()

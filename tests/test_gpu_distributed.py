@@ -104,11 +104,19 @@ def test_bench_under_a_launcher_single_rank_nccl():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--backend", "nccl", "--quick",
            "--steps", "20", "--warmup", "5", "--gather-steps", "8"]
-    p = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in _env().items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}      # as a foreign launcher would start the ranks
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = _result_line(p.stdout)
     assert out["n_gpus"] == 1 and out["per_rank"]["process_group"] and out["per_rank"]["backend"] == "nccl"
     assert len(out["per_rank"]["launch_us"]) == 1 and 2.0 < out["per_rank"]["launch_us"][0] < 50.0
+    # the line says how large the RCCL world was and which device every rank ran on; and a launcher-started rank (no spawn path of
+    # bench.py in between) gets HSA_ENABLE_IPC_MODE_LEGACY=0 from main() itself, before torch is imported
+    assert out["rccl_world"] == 1 and out["process_group_world"] == 1
+    devs = out["per_rank"]["devices"]
+    assert len(devs) == 1 and out["per_rank"]["distinct_devices"] == 1
+    assert devs[0]["rank"] == 0 and devs[0]["device_index"] == 0 and devs[0]["device_name"] and ":" in devs[0]["pci_bus_id"]
+    assert devs[0]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     for k in ("rccl_gather_to_rank0_ms", "rccl_gather_rollout_ms", "rccl_gather_rollout_message_bytes", "rccl_gather_rollout_expected_xgmi_ms"):
         assert out[k] > 0, k
     assert out["rccl_gather_rollout_message_bytes"] >= 8 * 65536 * 101
@@ -128,6 +136,9 @@ def test_bench_starts_its_own_ranks_from_a_plain_invocation():
     out = _result_line(p.stdout)
     assert out["n_gpus"] == 2 and out["config"]["global_envs"] == 2 * 65536 and "rehearsal" in out["config"]
     assert len(out["per_rank"]["launch_us"]) == 2 and out["per_rank"]["max_over_ranks_us"] == max(out["per_rank"]["launch_us"])
+    assert out["rccl_world"] is None and out["process_group_world"] == 2          # gloo: no RCCL world to report
+    devs = out["per_rank"]["devices"]
+    assert [d["rank"] for d in devs] == [0, 1] and len({d["pid"] for d in devs}) == 2 and out["per_rank"]["distinct_devices"] == 1
     assert out["value"] == pytest.approx(2 * 65536 * 20 / (out["ms_per_step"] * 20 * 1e-3), rel=1e-9)
     assert out["rccl_gather_rollout_steps"] == 4 and "cpu_baseline" not in out      # N>1: the headline leg and the gathers only
 

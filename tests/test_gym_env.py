@@ -156,38 +156,32 @@ def test_deepcopy_gives_an_independent_env_in_the_same_state():
     assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2 and f.t == 2.0
 
 
-REFERENCE_MC = "/root/reference/monte_carlo.py"
+def _oracle_env(params, **engine_kw):
+    from oracle_engine import OracleEngine
+    return RendezvousEnv(engine=OracleEngine(1, params, storage="f64", on_done="continue", **engine_kw), quiet=True)
 
 
-@pytest.mark.skipif(not __import__("os").path.exists(REFERENCE_MC), reason="needs the reference tree (build container only)")
-def test_the_reference_evaluate_loop_runs_unchanged_on_the_gym_object():
-    """Drop-in check of SURVEY §8b-i in the build container: the reference's OWN ``monte_carlo.evaluate(model, env, initial_state)``
-    (monte_carlo.py:94-207 — self-contained, NumPy only) is taken from its source text at test time, unmodified, and driven with
-    ``RendezvousEnv`` as ``env`` (oracle-backed engine: no GPU here) and ``MlpPolicy`` as ``model``.  Its 12 outputs for the first
-    rows of the published initial conditions must equal the reference's own re-run recorded in tests/golden/mc_reference_run.npz.
-    (Nothing of the reference is stored in the repo; the test is skipped where the reference tree does not exist.)"""
+def _policy():
     import os
     import torch
     from helpers import GOLDEN
-    from oracle_engine import OracleEngine
-    from reinforcement_learning_rendezvous_amd import monte_carlo as mc
     from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
-    src = open(REFERENCE_MC).read()
-    start = src.index("def evaluate(model, env, initial_state):")
-    end = src.index('if __name__ == "__main__":', start)
-    scope = {"np": np}
-    exec(compile(src[start:end], REFERENCE_MC, "exec"), scope)          # the reference's function object, as written
-    evaluate = scope["evaluate"]
     torch.set_num_threads(1)
-    model = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
-    env = RendezvousEnv(engine=OracleEngine(1, mc.make_eval_params(), storage="f64", on_done="continue", seed=0), quiet=True)
+    return MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+
+
+def check_mc_evaluate(evaluate, rows=40):
+    """``evaluate(model, env, initial_state)`` (the Monte Carlo episode loop, monte_carlo.py:94-207) drives ``RendezvousEnv``: its 12
+    outputs for the first published initial conditions against the reference's own recorded re-run (tests/golden/mc_reference_run.npz)."""
+    from reinforcement_learning_rendezvous_amd import monte_carlo as mc
+    model, env = _policy(), _oracle_env(mc.make_eval_params(), seed=0)
     ics = load_golden("mc_initial_conditions.npz")["states"]
     ref = load_golden("mc_reference_run.npz")
     cols = [str(c) for c in ref["columns"]]
     tol = dict(total_reward=5e-2, total_delta_v=1e-5, min_dist_from_koz=2e-4, pos_error=2e-5, vel_error=1e-5, att_error=5e-3,
                rot_error=2e-5)          # torch-f32 vs NumPy-f32 policy arithmetic, as in test_oracle_golden.py
     n_succ = n_coll = 0
-    for row in range(40):
+    for row in range(rows):
         s = ics[row]
         out = evaluate(model, env, dict(rc=s[0:3], vc=s[3:6], qc=s[6:10], wc=s[10:13], qt=s[13:17], wt=s[17:20]))
         assert list(out) == cols
@@ -196,39 +190,19 @@ def test_the_reference_evaluate_loop_runs_unchanged_on_the_gym_object():
         for c, t in tol.items():
             assert abs(out[c] - ref["table"][row, cols.index(c)]) <= t, (row, c, out[c], ref["table"][row, cols.index(c)])
         n_succ += out["succeeded"]; n_coll += out["collided"]
-    assert n_succ == int(ref["table"][:40, cols.index("succeeded")].sum()) and n_coll == int(ref["table"][:40, cols.index("collided")].sum())
+    assert n_succ == int(ref["table"][:rows, cols.index("succeeded")].sum()) and n_coll == int(ref["table"][:rows, cols.index("collided")].sum())
 
 
-REFERENCE_TRAJ = "/root/reference/save_new_trajectory.py"
-
-
-@pytest.mark.skipif(not __import__("os").path.exists(REFERENCE_TRAJ), reason="needs the reference tree (build container only)")
-def test_the_reference_trajectory_recorder_runs_unchanged_on_the_gym_object(capsys):
-    """As above for ``save_new_trajectory.evaluate(model, env, args)`` (save_new_trajectory.py:35-204): the reference's function, from
-    its source text, records an episode of ``RendezvousEnv`` — ``reset()``, ``get_observation``, every state attribute, ``get_errors``,
-    ``check_collision`` / ``check_success`` / ``dist_from_koz`` / ``collided`` / ``t`` after every step — and must return the arrays the
-    reference recorded for the same three initial states (tests/golden/eval_reference.npz; the env's reset replays them from a tape)."""
-    import os
-    import pickle
-    import types
-    import torch
-    from helpers import GOLDEN
-    from oracle_engine import OracleEngine
+def check_record_trajectory(record):
+    """``record(model, env) -> data`` (the trajectory recorder's episode loop, save_new_trajectory.py:35-204) on ``RendezvousEnv``: every
+    array of the three trajectories the reference recorded (tests/golden/eval_reference.npz; the env's reset replays their initial states)."""
     from reinforcement_learning_rendezvous_amd.params import make_params
-    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
-    src = open(REFERENCE_TRAJ).read()
-    start = src.index("def evaluate(model, env, args):")
-    end = src.index("def get_args():", start)
-    scope = {"np": np, "os": os, "pickle": pickle, "print_state": lambda env: None}      # print_state: a table printer (environment_utils.py:100)
-    exec(compile(src[start:end], REFERENCE_TRAJ, "exec"), scope)
-    evaluate = scope["evaluate"]
-    torch.set_num_threads(1)
-    model = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))
+    model = _policy()
     g = load_golden("eval_reference.npz")
     for j in range(3):
         s0 = g[f"traj{j}_state0"]
-        env = RendezvousEnv(engine=OracleEngine(1, make_params(), storage="f64", on_done="continue", tape=s0[None, None, :]), quiet=True)
-        data = evaluate(model, env, types.SimpleNamespace(save=False))       # note: like the reference's, this env object is spent afterwards
+        env = _oracle_env(make_params(), tape=s0[None, None, :])
+        data = record(model, env)
         for k in ("rc", "vc", "qc", "wc", "qt", "wt", "a", "rew", "errors", "t"):
             want = g[f"traj{j}_{k}"]
             assert data[k].shape == want.shape, (j, k, data[k].shape, want.shape)
@@ -237,41 +211,97 @@ def test_the_reference_trajectory_recorder_runs_unchanged_on_the_gym_object(caps
         d_koz, collisions, successes = g[f"traj{j}_scalars"]
         assert data["d_koz"] == pytest.approx(d_koz, abs=1e-4)
         assert data["collisions"] == int(collisions) and data["successes"] == int(successes)
-    capsys.readouterr()
 
 
-REFERENCE_CB = "/root/reference/custom/custom_callbacks.py"
-
-
-@pytest.mark.skipif(not __import__("os").path.exists(REFERENCE_CB), reason="needs the reference tree (build container only)")
-def test_the_reference_training_callback_evaluation_runs_unchanged_on_the_gym_object(capsys):
-    """And for ``CustomWandbCallback.evaluate_policy(self)`` (custom/custom_callbacks.py:186-300), the evaluation the reference runs
-    during training: the method body, from its source text, with ``self.env = RendezvousEnv`` (24 resets replayed from the recorded
-    tape), ``self.model = MlpPolicy``, ``self.n_evals = 24`` — ``target2lvlh(rd)``, ``get_pos_error``, ``get_attitude_error``,
-    ``check_collision``, ``t``, ``success``, ``rc``, ``total_delta_v`` / ``total_delta_w``, ``dt`` — must log the 12 means the
-    reference logged (tests/golden/eval_reference.npz)."""
-    import os
-    import textwrap
-    import types
-    import torch
-    from helpers import GOLDEN
-    from oracle_engine import OracleEngine
+def check_callback_evaluation(evaluate_policy):
+    """``evaluate_policy(model, env, n_evals) -> means`` (the evaluation run during training, custom/custom_callbacks.py:186-300) on
+    ``RendezvousEnv`` (24 resets replayed from the recorded tape): the 12 means the reference logged (tests/golden/eval_reference.npz)."""
     from reinforcement_learning_rendezvous_amd.params import make_params
-    from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
-    src = open(REFERENCE_CB).read()
-    start = src.index("    def evaluate_policy(self):")
-    end = src.index("        return output", start) + len("        return output")
-    scope = {"np": np}
-    exec(compile(textwrap.dedent(src[start:end]), REFERENCE_CB, "exec"), scope)
-    torch.set_num_threads(1)
     g = load_golden("eval_reference.npz")
-    env = RendezvousEnv(engine=OracleEngine(1, make_params(), storage="f64", on_done="continue", tape=g["cb_tape"][:, None, :]), quiet=True)
-    me = types.SimpleNamespace(model=MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz")), env=env, n_evals=24)
-    out = scope["evaluate_policy"](me)
+    env = _oracle_env(make_params(), tape=g["cb_tape"][:, None, :])
+    out = evaluate_policy(_policy(), env, 24)
     ref = dict(zip([str(k) for k in g["cb_metric_names"]], g["cb_metrics"]))
     assert list(out) == list(ref)
     for k in ("ep_len", "ep_success", "ep_collision_percentage", "ep_time_of_first_collision", "%_collided_episodes", "%_successfull_episodes"):
         assert out[k] == pytest.approx(ref[k], rel=1e-12), k                  # step counts: exact
     for k in ("ep_rew", "ep_dist", "ep_delta_v", "ep_delta_w", "ep_min_pos_error", "ep_avg_att_error"):
         assert out[k] == pytest.approx(ref[k], rel=2e-5), k                   # NumPy-f32 vs torch-f32 policy arithmetic
+
+
+# The reference's three single-env caller loops, restated in tests/reference_callers.py (cited line by line), drive the Gym object and
+# reproduce the reference's recorded outputs: stored in the repo, runs everywhere (CPU: the oracle-backed engine).
+def test_monte_carlo_episode_loop_on_the_gym_object():
+    import reference_callers as rc
+    check_mc_evaluate(rc.mc_evaluate)
+
+
+def test_trajectory_recorder_loop_on_the_gym_object(capsys):
+    import reference_callers as rc
+    check_record_trajectory(rc.record_trajectory)
     capsys.readouterr()
+
+
+def test_training_callback_evaluation_loop_on_the_gym_object(capsys):
+    import reference_callers as rc
+    check_callback_evaluation(rc.callback_evaluate_policy)
+    capsys.readouterr()
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not (__import__("os").environ.get("RDV_RUN_REFERENCE_SOURCE") == "1" and __import__("os").path.isdir(REFERENCE)),
+                    reason="opt-in (RDV_RUN_REFERENCE_SOURCE=1, build container only): executes text of the untrusted reference tree")
+def test_the_reference_functions_run_unchanged_on_the_gym_object_in_a_child_process():
+    """Opt-in drop-in check: the reference's OWN three functions, taken from their source text (unmodified), drive ``RendezvousEnv`` and
+    must pass the same three checks.  The reference tree is untrusted public content, so this never runs by default and never in the
+    pytest process: a child interpreter (``-I``: no user site, no PYTHON* variables; a scratch working directory; a time limit) executes
+    tests/_reference_source_child.py, which hands the reference's code ``np`` and nothing else — no ``os``, no ``pickle``."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    with tempfile.TemporaryDirectory() as scratch:
+        r = subprocess.run([sys.executable, "-I", os.path.join(here, "_reference_source_child.py"), REFERENCE], cwd=scratch,
+                           capture_output=True, text=True, timeout=900, env={"PATH": "/usr/bin:/bin", "HOME": scratch, "OMP_NUM_THREADS": "1"})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "3 reference functions ran unchanged" in r.stdout
+
+
+def test_constructor_takes_the_reference_positional_order(monkeypatch, capsys):
+    """``RendezvousEnv(rc0, vc0, ..., wt0_range, reward_kwargs, koz_radius, corridor_half_angle, h, dt, t_max, quiet)`` — the reference's
+    positional order (rendezvous_env.py:17-37; reward_kwargs is the 13th, not the 18th): all 19 arguments given positionally bind as the
+    same call written with keywords; too many, duplicates, and kwargs beside an injected engine are refused; and the episode-end line
+    prints the clock as the reference's Python arithmetic on the caller's dt does (int dt: '2', float dt: '2.0'; :193, :380)."""
+    import inspect
+    import reinforcement_learning_rendezvous_amd.batch as batch_mod
+    from oracle_engine import OracleEngine
+    from reinforcement_learning_rendezvous_amd.params import make_params
+    monkeypatch.setattr(batch_mod, "RendezvousBatch", lambda n, params=None, device=None, storage="f64", on_done="reset", seed=0:
+                        OracleEngine(n, params, storage=storage, on_done=on_done, seed=seed))
+    ref_order = ["rc0", "vc0", "qc0", "wc0", "qt0", "wt0", "rc0_range", "vc0_range", "qc0_range", "wc0_range", "qt0_range", "wt0_range",
+                 "reward_kwargs", "koz_radius", "corridor_half_angle", "h", "dt", "t_max", "quiet"]          # rendezvous_env.py:17-37
+    assert list(inspect.signature(make_params).parameters) == ref_order
+    kw = dict(rc0=np.array([0.0, -14.0, 0.0]), vc0=np.array([0.0, 0.01, 0.0]), qc0=np.array([1.0, 0.0, 0.0, 0.0]), wc0=np.zeros(3),
+              qt0=np.array([1.0, 0.0, 0.0, 0.0]), wt0=np.array([0.0, 0.0, 0.02]), rc0_range=0.5, vc0_range=0.05, qc0_range=0.02,
+              wc0_range=0.002, qt0_range=0.3, wt0_range=0.01, reward_kwargs=dict(collision_coef=0.7, bonus_coef=5.0, fuel_coef=0.1, att_coef=2.0),
+              koz_radius=6.0, corridor_half_angle=0.4, h=500e3, dt=2, t_max=50, quiet=True)
+    by_position = RendezvousEnv(*[kw[k] for k in ref_order])
+    by_keyword = RendezvousEnv(**kw)
+    assert by_position.batch.params.to_dict() == by_keyword.batch.params.to_dict() == make_params(**kw).to_dict()
+    assert by_position.koz_radius == 6.0 and by_position.dt == 2 and by_position.t_max == 50 and by_position.quiet is True
+    assert by_position.reward_kwargs == kw["reward_kwargs"]
+    with pytest.raises(TypeError):
+        RendezvousEnv(*([None] * 20))
+    with pytest.raises(TypeError):
+        RendezvousEnv(kw["rc0"], rc0=kw["rc0"])
+    with pytest.raises(TypeError):
+        RendezvousEnv(engine=by_keyword.batch, t_max=60)
+    capsys.readouterr()
+    for dt, shown in ((2, "t =    2 |"), (2.0, "t =  2.0 |")):
+        e = RendezvousEnv(dt=dt, t_max=2)          # one step and the time limit ends the episode (:368)
+        e.reset()
+        _, _, done, _ = e.step(np.zeros(6, np.float32))
+        assert done
+        assert shown in capsys.readouterr().out, (dt, shown)

@@ -212,6 +212,11 @@ def _worker(rank, world, port, n_global, steps, q):
     assert unequal_refused
     total = sharding.reduce_stats(env.get_stats())
     cols = sharding.gather_columns({"lo": np.full(hi - lo, lo), "ret": env.get_aux()[:, 6].numpy()})
+    ragged = sharding.gather_columns({"k": np.arange(3 + rank, dtype=np.int64), "x": np.linspace(0.0, 1.0, 3 + rank)})   # shards of 3 and 4 rows
+    if rank == 0:
+        assert ragged["k"].dtype == np.int64 and ragged["k"].tolist() == [0, 1, 2, 0, 1, 2, 3] and ragged["x"].shape == (7,) and ragged["x"][3] == 0.0
+    else:
+        assert ragged is None
     # ---- per-rollout gather: T steps of the closed loop written INTO the message, one dist.gather per rollout
     T = 5
     pol = MlpPolicy.from_npz(os.path.join(GOLDEN, "mlp_policy.npz"))

@@ -44,8 +44,9 @@ K = 100
 for k in range(K):
     vec.step(acts[k % 8])
 vec._trace = None
-ph = np.array(ph)[:, :4] * 1e3
-names = ["step kernel + the message's D2H (synchronises)", "done mask", "finished rows picked on the host", "infos dicts"]
+ph = np.array(ph)[:, :5] * 1e3
+names = ["step kernel + the message's D2H (synchronises)", "done mask + output views", "finished entries re-pointed + flatnonzero",
+         "finished rows picked on the host", "infos dicts of the finished envs"]
 print(f"phase breakdown (ms per step, {K} steps): mean | median | max")
 for j, nm in enumerate(names):
     print(f"   {nm:50s} {ph[:, j].mean():6.3f} {np.median(ph[:, j]):6.3f} {ph[:, j].max():6.3f}")
