@@ -224,9 +224,14 @@ int rdv_set_kernel_variant(rdv_handle h, int variant);
  * max_delta_w (:82, derived from inertia[0][0] in the constructor) is an RdvParams field and is not touched here.
  */
 typedef enum RdvIntegrator {
-  RDV_INTEGRATOR_AUTO = 0,   /* EXACT when both tensors are c * Identity and both torques are zero, RK45 otherwise */
-  RDV_INTEGRATOR_EXACT = 1,  /* closed form q (x) exp(w dt / 2); refused (RDV_ERR_BAD_PARAMS) when it does not apply */
-  RDV_INTEGRATOR_RK45 = 2    /* the reference's own scheme: Dormand-Prince 5(4) with scipy's step-size control, per env */
+  RDV_INTEGRATOR_AUTO = 0,   /* PER BODY: the closed form for a body whose tensor is c * Identity and whose torque is zero, RK45 for the
+                                other (a tumbling tri-axial target beside the reference's chaser integrates the target only) */
+  RDV_INTEGRATOR_EXACT = 1,  /* closed form q (x) exp(w dt / 2); refused (RDV_ERR_BAD_PARAMS) when it does not apply to both bodies */
+  RDV_INTEGRATOR_RK45 = 2    /* the reference's own scheme for both bodies: Dormand-Prince 5(4) with scipy's step-size control, per env.
+                                The kernel evaluates the right-hand side's two quaternion normalisations with a reciprocal square root
+                                and the controller's error_norm^(-1/5) with a Newton-refined estimate (a few ulp from the reference's
+                                divisions / pow): it takes scipy's accepted / rejected steps unless an error norm lies within ~1e-15
+                                of 1, and lands within 1e-10 of the reference's state (tests/test_gpu_rigid_body.py) */
 } RdvIntegrator;
 
 typedef struct RdvRigidBody {

@@ -71,6 +71,7 @@ struct DevParams {
   // constant body torque of the chaser [0] and the target [1]; tolerances of the env's solve_ivp calls (:567-568)
   double body_inertia[2][9], body_inv_inertia[2][9], body_torque[2][3];
   double rk_rtol, rk_atol;
+  int32_t body_general[2];                // per body (chaser, target): integrate with RK45 (else the closed form applies to it)
 };
 
 enum : uint32_t { FLAG_COLLIDED = 1u, FLAG_HALTED = 2u, SUCCESS_SHIFT = 2 };   // flags word: bit0, bit1, count << 2
@@ -230,12 +231,17 @@ __device__ __forceinline__ void integrate_attitude(double* q, const double* w, d
 // This is the same Dormand-Prince 5(4) pair with scipy's initial-step rule and step-size controller, operation for operation
 // (fused multiply-adds off in this section), in fp64: it takes the same accepted / rejected steps as scipy and lands within
 // rounding of its result.  Each lane runs its own adaptive loop (divergent trip counts; typically 1-3 steps per dt).
+// The right-hand side normalises the quaternion twice (dynamics.py:109 derivative_of_att_and_rot_rate, then :134 quat_derivative):
+// q / |q| each time.  Here each is ONE reciprocal square root (v_rsq_f64 + two Newton steps, <= 2 ulp: rsqrt64) and four products
+// instead of a square root and four divisions: 24 instructions instead of ~136 of a right-hand side of ~160, evaluated 7 times per
+// attempted step (round 4: tri-axial target 28 -> see profiles/r04_rigid_time.txt).  The quotients differ from the reference's by an
+// ulp or two; the step sequence (accept / reject, step sizes) is scipy's unless an error norm lies within ~1e-15 of 1.
 __device__ __forceinline__ void rigid_rhs(const double* I, const double* Iinv, const double* tau, const double* y, double* dy) {
 #pragma clang fp contract(off)
-  const double mag = sqrt(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);           // dynamics.py:109
-  const double a0 = y[0] / mag, a1 = y[1] / mag, a2 = y[2] / mag, a3 = y[3] / mag;
-  const double mag2 = sqrt(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);                           // dynamics.py:134
-  const double q0 = a0 / mag2, q1 = a1 / mag2, q2 = a2 / mag2, q3 = a3 / mag2;
+  const double inv1 = rsqrt64(y[0] * y[0] + y[1] * y[1] + y[2] * y[2] + y[3] * y[3]);       // dynamics.py:109
+  const double a0 = y[0] * inv1, a1 = y[1] * inv1, a2 = y[2] * inv1, a3 = y[3] * inv1;
+  const double inv2 = rsqrt64(a0 * a0 + a1 * a1 + a2 * a2 + a3 * a3);                       // dynamics.py:134
+  const double q0 = a0 * inv2, q1 = a1 * inv2, q2 = a2 * inv2, q3 = a3 * inv2;
   const double w1 = y[4], w2 = y[5], w3 = y[6];
   dy[0] = 0.5 * (-w1 * q1 - w2 * q2 - w3 * q3);                                              // dynamics.py:137-151
   dy[1] = 0.5 * (w1 * q0 + w3 * q2 - w2 * q3);
@@ -257,6 +263,26 @@ __device__ __forceinline__ double rms7(const double* x) {
 #pragma unroll
   for (int i = 0; i < 7; ++i) s += x[i] * x[i];
   return sqrt(s) / sqrt(7.0);
+}
+
+// x^(-1/5) for x > 0 — the step-size controller's 0.9 * error_norm^(-1/5) (scipy rk.py) and the initial step's x^(1/5) = x * (x^(-1/5))^4.
+// libm's pow is ~230 instructions a call, and a wave whose lanes split over "accepted" and "rejected" runs both calls of an attempt:
+// the controller cost a third of an attempted step.  Here: x = m 2^e with e = 5k + j, so x^(-1/5) = 2^(-k) (m 2^j)^(-1/5) with
+// t = m 2^j in [0.5, 16); a float32 estimate of t^(-1/5) from the hardware's log2 / exp2 (relative error ~1e-6) and two Newton steps
+// y <- y (6 - t y^5) / 5 in fp64 (error e -> 3 e^2: 1e-6 -> 3e-12 -> below an ulp).  Within a few ulp of pow; ~35 instructions.
+__device__ __forceinline__ double pow_minus_fifth(double x) {
+  if (!(x < 1e300)) return 0.0;                      // huge / inf / NaN: the callers clamp the factor from below (0.2) anyway
+  int e;
+  const double m = frexp(x, &e);                     // x = m 2^e, m in [0.5, 1)
+  const int k = (e >= 0 ? e : e - 4) / 5;            // floor(e / 5)
+  const double t = ldexp(m, e - 5 * k);              // [0.5, 16)
+  double y = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf((float)t));
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double y2 = y * y;
+    y = (y * fma(-t, y2 * y2 * y, 6.0)) * 0.2;
+  }
+  return ldexp(y, -k);
 }
 
 constexpr int kRk45MaxAttempts = 4096;   // a lane that has not finished dt by then gets a NaN state (scipy would be failing too)
@@ -291,7 +317,11 @@ __device__ __forceinline__ void integrate_attitude_rk45(double* q, double* w, co
 #pragma unroll
     for (int i = 0; i < 7; ++i) sa[i] = (f1[i] - f[i]) / scale[i];
     const double d2 = rms7(sa) / h0;
-    const double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? fmax(1e-6, h0 * 1e-3) : pow(0.01 / fmax(d1, d2), 1.0 / 5.0);
+    double h1 = fmax(1e-6, h0 * 1e-3);
+    if (!(d1 <= 1e-15 && d2 <= 1e-15)) {             // (0.01 / max(d1, d2))^(1/5) = x * (x^(-1/5))^4
+      const double x = 0.01 / fmax(d1, d2), r = pow_minus_fifth(x), r2 = r * r;
+      h1 = x * (r2 * r2);
+    }
     h_abs = fmin(fmin(100 * h0, h1), t_bound);
   }
   double t = 0.0;
@@ -341,7 +371,7 @@ __device__ __forceinline__ void integrate_attitude_rk45(double* q, double* w, co
     const double error_norm = rms7(err);
     ++attempts;
     if (error_norm < 1) {
-      double factor = error_norm == 0 ? 10.0 : fmin(10.0, 0.9 * pow(error_norm, -0.2));
+      double factor = error_norm < 1e-8 ? 10.0 : fmin(10.0, 0.9 * pow_minus_fifth(error_norm));   // (below 1e-8 the power exceeds 10 / 0.9)
       if (rejected && factor > 1) factor = 1;
       h_abs *= factor;
       t = t_new;
@@ -352,7 +382,7 @@ __device__ __forceinline__ void integrate_attitude_rk45(double* q, double* w, co
       if (h_abs < min_step) h_abs = min_step;
     } else {
       if (!(error_norm == error_norm) || h_abs <= min_step) { failed = true; break; }   // non-finite state / step size too small
-      h_abs *= fmax(0.2, 0.9 * pow(error_norm, -0.2));
+      h_abs *= fmax(0.2, 0.9 * pow_minus_fifth(error_norm));
       if (h_abs < min_step) h_abs = min_step;
       rejected = true;
     }
@@ -709,13 +739,23 @@ struct StepResult {   // (the observation goes to the caller's sink: see observa
 // transition: a kernel that fetches ahead (step_kernel_tiles) issues its look-ahead loads there, BEHIND that entry in the in-order
 // vector-memory counter, so that waiting for the entry does not mean waiting for the look-ahead.
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
-template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink, typename Hook = NoHook>
-__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink, Hook&& mid = Hook()) {
+
+// What the first half of a transition hands to the second (step_env = step_env_chaser + step_target + step_env_finish).
+struct StepCtx {
+  float sum_v, sum_w;      // :201-202, :333: the action enters the bookkeeping and the reward only through these two float32 sums
+  double inv_dist, att;    // 1/|rc| and the attitude error (the table entry requested at the end of the chaser half)
+};
+
+// First half (:172-181): impulse, Clohessy-Wiltshire propagation, the chaser's rate impulse and attitude step, then the chaser's half
+// of the derived quantities.  kGeneral: a body whose inertia tensor / torque is not the reference's (rdv_set_rigid_body) is integrated
+// with the reference's own scheme (RK45, both its attitude and its rate evolve) — PER BODY (P.body_general[0 | 1], wave-uniform): a
+// tumbling tri-axial target beside the reference's chaser leaves the chaser on the closed form.
+template <typename ST, bool kGeneral = false, bool kRaw = false>
+__device__ __forceinline__ void step_env_chaser(const DevParams& P, Env& e, const float* a, Derived& d, StepCtx& c) {
   const ST tag = ST(0);
-  // :201-202, :333 need the action only through these two float32 sums: formed here, so that the six action registers die with the
-  // impulses below instead of living to the end of the transition
-  const float sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
-  const float sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
+  // formed here, so that the six action registers die with the impulses below instead of living to the end of the transition
+  c.sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
+  c.sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
   double Rc0[9];
   quat2mat(e.qc, Rc0);
@@ -737,27 +777,36 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   for (int i = 0; i < 3; ++i) e.wc[i] = fma((double)a[3 + i], P.max_delta_w, e.wc[i]);
   // Chaser side first (:181), then its half of the derived quantities: the attitude error's table entry (the one dependent memory
   // access of a transition) is requested here and is needed ~500 instructions later, for the reward.
-  if (kGeneral) integrate_attitude_rk45(e.qc, e.wc, P.body_inertia[0], P.body_inv_inertia[0], P.body_torque[0], P.dt, P.rk_rtol, P.rk_atol);   // general inertia / torque: the reference's own integrator (both rates evolve)
-  else integrate_attitude<kRaw>(e.qc, e.wc, P.half_dt);
+  if (kGeneral && P.body_general[0]) integrate_attitude_rk45(e.qc, e.wc, P.body_inertia[0], P.body_inv_inertia[0], P.body_torque[0], P.dt, P.rk_rtol, P.rk_atol);
+  else integrate_attitude<kRaw || kGeneral>(e.qc, e.wc, P.half_dt);   // (the general kernels also run the first step after rdv_set_state)
 #pragma unroll
   for (int i = 0; i < 3; ++i) e.wc[i] = canon(e.wc[i], tag);
 #pragma unroll
   for (int i = 0; i < 4; ++i) e.qc[i] = canon(e.qc[i], tag);
-  double inv_dist;
-  derive_chaser(P, e, d, inv_dist);
-  const double att = attitude_error_of(P, d.k_att);
-  mid();
-  // target side (:184)
+  derive_chaser(P, e, d, c.inv_dist);
+  c.att = attitude_error_of(P, d.k_att);
+}
+
+// The target's attitude step (:184) on (qt, wt) alone: what a partner wave can run beside the chaser half (step_kernel_general).
+// The result is NOT yet canonical: step_env_finish rounds it to the storage type.
+template <bool kGeneral = false, bool kRaw = false>
+__device__ __forceinline__ void step_target(const DevParams& P, double* qt, double* wt) {
+  if (kGeneral && P.body_general[1]) integrate_attitude_rk45(qt, wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);
+  else integrate_attitude<kRaw || kGeneral>(qt, wt, P.half_dt);
+}
+
+// Second half (:187-221): the target's state made canonical, its half of the derived quantities, the latches, bookkeeping, reward,
+// observation and termination.
+template <typename ST, bool kLazy, bool kGeneral = false, typename Sink>
+__device__ __forceinline__ void step_env_finish(const DevParams& P, Env& e, StepResult& r, Derived& d, const StepCtx& c, Sink&& sink) {
+  const ST tag = ST(0);
   if (kGeneral) {
-    integrate_attitude_rk45(e.qt, e.wt, P.body_inertia[1], P.body_inv_inertia[1], P.body_torque[1], P.dt, P.rk_rtol, P.rk_atol);
 #pragma unroll
     for (int i = 0; i < 3; ++i) e.wt[i] = canon(e.wt[i], tag);
-  } else {
-    integrate_attitude<kRaw>(e.qt, e.wt, P.half_dt);
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) e.qt[i] = canon(e.qt[i], tag);
-  derive_target<kLazy>(P, e, d, inv_dist);
+  derive_target<kLazy>(P, e, d, c.inv_dist);
   const bool inst_coll = in_koz(P, d);
   // :187-190
   if (!(e.flags & FLAG_COLLIDED)) {
@@ -767,13 +816,14 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   e.k += 1;                                                           // :193 t = round(k*dt, 3)
   e.bubble = canon(fmax(e.bubble - P.bubble_decrease_rate, P.bubble_min), tag);   // :196-198
   // :201-202; float32 sums, see the promotion table in oracle/rdv_oracle.c
-  e.sum_dv = (double)((float)e.sum_dv + mul_f32_rn(sum_v, P.max_delta_v_f32));
-  e.sum_dw = canon(fma((double)sum_w, P.max_delta_w, e.sum_dw), tag);
+  e.sum_dv = (double)((float)e.sum_dv + mul_f32_rn(c.sum_v, P.max_delta_v_f32));
+  e.sum_dw = canon(fma((double)c.sum_w, P.max_delta_w, e.sum_dw), tag);
 
   // :313-353 (the reward does not depend on the observation or on done: computed first, the observation last, so that its 17 floats
   // go straight to the sink)
+  const double att = c.att;
   double rew = P.att_term * fma(-att, P.inv_max_attitude_error, 1.0);                  // :329
-  rew += (double)(mul_f32_rn(P.fuel_scale_f32, sum_v) / P.fuel_div_f32);               // :333
+  rew += (double)(mul_f32_rn(P.fuel_scale_f32, c.sum_v) / P.fuel_div_f32);             // :333
   if (inst_coll) rew -= P.coll_term;                                                   // :336-337
   if (d.r2 <= P.lt2_koz && !(e.flags & FLAG_COLLIDED) && d.pos2 <= P.lt2_rd) {             // :340, :348 (both strict: lt2_*)
     rew += P.bonus_term * fma(-sqrt(d.pos2), P.inv_max_rd_error, 2.0);                 // :349
@@ -783,9 +833,6 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   r.reward = (float)rew;
   r.reward64 = rew;
   // :205, :355-386
-  // Box.contains (:367): outside <=> some |v| > 1 or NaN <=> the largest (bits & 0x7fffffff) exceeds the bits of 1.0f (NaNs lie above
-  // infinity there).  One integer maximum over the 17 elements and one comparison, instead of 17 float comparisons each writing a
-  // lane mask that the scalar unit then has to OR together.
   bool outside = false;
   observation_to(P, e, [&](int j, float v) {
     outside |= !(fabsf(v) <= 1.0f);                                                    // Box.contains; NaN -> outside
@@ -799,6 +846,16 @@ __device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float
   const bool c_time = e.k >= P.k_time, c_att = d.k_att <= P.ka_done_max;
   r.done = (outside | c_time | c_bubble | c_att) ? 1 : 0;
   r.reason = outside ? 1 : (c_time ? 2 : (c_bubble ? 3 : (c_att ? 4 : 0)));            // :381 first true
+}
+
+// step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
+template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink, typename Hook = NoHook>
+__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink, Hook&& mid = Hook()) {
+  StepCtx c;
+  step_env_chaser<ST, kGeneral, kRaw>(P, e, a, d, c);
+  mid();
+  step_target<kGeneral, kRaw>(P, e.qt, e.wt);      // :184
+  step_env_finish<ST, kLazy, kGeneral>(P, e, r, d, c, sink);
 }
 
 // diagnostics row (RDV_DIAG_DIM = 8) — evaluator-only

@@ -10,6 +10,6 @@ CSRC = os.path.join(ROOT, "reinforcement_learning_rendezvous_amd", "csrc")
 def build_variant(out, extra=()):
     """`make` both translation units with `extra` compiler flags (e.g. ["-DRDV_STAMPS"]) and link them into `out`."""
     obj = tempfile.mkdtemp(prefix="rdv_obj_")
-    subprocess.check_call(["make", "-C", CSRC, "-B", "-j2", f"OUT={os.path.abspath(out)}", f"OBJ={obj}", "EXTRA=" + " ".join(extra)],
+    subprocess.check_call(["make", "-C", CSRC, "-B", "-j3", f"OUT={os.path.abspath(out)}", f"OBJ={obj}", "EXTRA=" + " ".join(extra)],
                           stdout=subprocess.DEVNULL)
     return out

@@ -99,7 +99,7 @@ def main():
             extra.append(a)
     os.makedirs(OUT, exist_ok=True)
     flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wno-unused-function", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
-    if tu == "rdv_tiles.hip":
+    if tu in ("rdv_tiles.hip", "rdv_general.hip"):
         flags += ["-mllvm", "-disable-machine-licm"]
     subprocess.run(["/opt/rocm/bin/hipcc"] + extra + flags + ["-gline-tables-only", "-save-temps", "-c", "-o", "/dev/null", os.path.join(CSRC, tu)],
                    cwd=OUT, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

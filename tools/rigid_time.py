@@ -15,6 +15,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 cases = [("closed form (reference bodies)", {}),
          ("rk45 forced on the reference bodies", dict(integrator="rk45")),
          ("tri-axial target 9/16/27, tumbling 3 deg/s", dict(inertia_target=[9.0, 16.0, 27.0])),
+         ("anisotropic chaser + torque, reference target", dict(inertia=[[14.0, 0.6, -0.4], [0.6, 18.5, 0.9], [-0.4, 0.9, 22.0]], torque=[0.01, 0.0, -0.01])),
          ("both bodies anisotropic + torques", dict(inertia=[[14.0, 0.6, -0.4], [0.6, 18.5, 0.9], [-0.4, 0.9, 22.0]],
                                                    inertia_target=[9.0, 16.0, 27.0], torque=[0.01, 0.0, -0.01],
                                                    torque_target=[0.0, 0.02, 0.0]))]
