@@ -100,18 +100,42 @@ __device__ __forceinline__ void wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-// x[j] = hi[j] + lo[j] to 22 bits (x already scaled: |x| < 65504); the subtraction is exact in fp32.  Two values at a time, so that
-// the conversions are the packed ones (v_cvt_pk_f16_f32) and the subtraction one v_pk_add_f32: 5 instructions per pair (written value by
-// value the compiler converted every hi twice — once for the residual, once into the pair — 8 per pair).
+// x[j] = hi[j] + lo[j] to 22 bits (x already scaled: |x| < 65504); the subtraction is exact in fp32.  Two values at a time: the pair of
+// hi terms by one packed conversion (v_cvt_pk_f16_f32), each lo term by ONE mixed-precision fma that reads the fp16 hi term in place,
+// forms x - hi exactly and rounds it to fp16 into its half of the result (v_fma_mixlo_f16 / v_fma_mixhi_f16): 13 instructions per 8 values.
+// Round 3 converted the hi pair back to fp32 (two v_cvt_f32_f16), subtracted packed and converted again: 5 per pair, 64 more per
+// actor wave; the same values bit for bit.
 typedef _Float16 pol_h2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2(const float (&x)[8], f16x8 (&t)[2]) {
+  uint32_t hi[4], lo[4];
 #pragma unroll
-  for (int j = 0; j < 8; j += 2) {
-    const pol_f2 v = {x[j], x[j + 1]};
-    const pol_h2 hi = __builtin_convertvector(v, pol_h2);
-    const pol_f2 r = v - __builtin_convertvector(hi, pol_f2);
-    const pol_h2 lo = __builtin_convertvector(r, pol_h2);
-    t[0][j] = hi.x; t[0][j + 1] = hi.y; t[1][j] = lo.x; t[1][j + 1] = lo.y;
+  for (int p = 0; p < 4; ++p) {
+    const pol_f2 v = {x[2 * p], x[2 * p + 1]};
+    const pol_h2 h = __builtin_convertvector(v, pol_h2);
+    __builtin_memcpy(&hi[p], &h, 4);
+  }
+  // ONE block for the four pairs: the compiler's hazard recogniser does not see into inline asm, and these are half-register writes —
+  // a reader of such a register needs a wait state behind the write (written pair by pair, the rollout kernel's schedule put a
+  // consumer right behind one and read the old half: actions off by 1e-3).  Inside the block every register's two writes are four
+  // instructions apart; the closing s_nop keeps whatever the compiler places next at a distance.  (x * 1 - hi written in C is
+  // folded to a subtraction, and the compiler then converts hi back instead of selecting the mixed-precision fma.)
+  asm("v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+      "s_nop 0"
+      : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3])
+      : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(hi[0]), "v"(hi[1]), "v"(hi[2]), "v"(hi[3]));
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    pol_h2 h, l;
+    __builtin_memcpy(&h, &hi[p], 4);
+    __builtin_memcpy(&l, &lo[p], 4);
+    t[0][2 * p] = h.x; t[0][2 * p + 1] = h.y; t[1][2 * p] = l.x; t[1][2 * p + 1] = l.y;
   }
 }
 
