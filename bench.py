@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="wall-clock budget of the all-core CPU sample")
     ap.add_argument("--no-policy", action="store_true", help="skip the informational MLP-policy rollout leg")
     ap.add_argument("--no-large-n", action="store_true", help="skip the 4,194,304-env leg (fused layout beyond the Infinity Cache)")
+    ap.add_argument("--only-large-n", type=int, default=0, metavar="N",
+                    help="run ONLY the large-batch leg at N envs (five fresh allocations) and print its JSON: the program of a per-size rocprofv3 run")
     ap.add_argument("--no-gather", action="store_true", help="under torch.distributed: skip timing the RCCL gathers of rollouts to rank 0")
     ap.add_argument("--gather-steps", type=int, default=64, help="steps per rollout of the per-rollout gather leg (one message per rank per rollout)")
     ap.add_argument("--quick", action="store_true", help="the headline leg only (= --no-cpu-baseline --no-policy --no-large-n)")
@@ -153,6 +155,9 @@ def main():
     args = parse()
     if args.quick:
         args.no_cpu_baseline = args.no_policy = args.no_large_n = True
+    if args.only_large_n:
+        args.no_cpu_baseline = args.no_policy = True
+        args.steps, args.warmup = min(args.steps, 64), min(args.warmup, 16)     # (the headline leg still runs, briefly: its kernel has another name)
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not under_launcher:
         spawn_ranks(args)          # does not return
@@ -477,7 +482,7 @@ def main():
         env.reset()
 
     # ---- the same metric with fp64 state storage (parity mode), N=1 only
-    if rank == 0 and world == 1 and args.storage == "f32":
+    if rank == 0 and world == 1 and args.storage == "f32" and not args.only_large_n:
         try:
             e64 = RendezvousBatch(n, device=device, storage="f64", seed=0)
             e64.reset()
@@ -488,61 +493,66 @@ def main():
         except Exception as exc:  # pragma: no cover
             out["f64_storage"] = {"error": repr(exc)}
 
+    def large_leg(n_big, allocations, steps, reps, seed, n_acts):
+        """rdv_step (fused by-part kernel) at `n_big` envs on FRESH allocations of the batch, each timed after 0.1 s of sustained load:
+        beyond the Infinity Cache the launch time of one and the same build has modes by box, allocation and moment,
+        so the leg reports min / median / max over the allocations and every value, not one draw."""
+        gen_b = torch.Generator(device=device).manual_seed(seed)
+        acts_b = [(torch.rand((n_big, 6), device=device, generator=gen_b) * 2 - 1).contiguous() for _ in range(n_acts)]
+        trials = []
+        for _trial in range(allocations):
+            big = RendezvousBatch(n_big, device=device, storage=args.storage, seed=0)
+            big.reset()
+            for t in range(24):
+                big.step(acts_b[t % n_acts])
+            trials.append(timed_steps(big, acts_b, steps, reps))
+            big.close(); del big
+            torch.cuda.empty_cache()
+        del acts_b
+        torch.cuda.empty_cache()
+        order = sorted(trials)
+        us = {"min": order[0], "median": order[len(order) // 2], "max": order[-1]}
+        frac = {k: ALGO_BYTES_PER_ENV_STEP * n_big / (v * 1e-6) / 1e9 / HBM_PEAK_GBPS for k, v in us.items()}
+        ach = frac["median"] * HBM_PEAK_GBPS
+        tr = pmc.get(f"{args.storage}_{n_big}") if rank == 0 else None
+        return {"value": n_big / (us["median"] * 1e-6), "unit": "env steps/s", "envs": n_big, "launch_us": us["median"],
+                "launch_us_min_median_max": [us["min"], us["median"], us["max"]], "launch_us_per_allocation": trials,
+                "kernel": "rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>"),
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac["median"],
+                             "frac_at_min_median_max_launch_us": [frac["min"], frac["median"], frac["max"]],
+                             "traffic": tr["bytes_per_launch"] if tr else None,
+                             "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" if tr else None,
+                             "rocprof_row": f"profiles/r04_kernel_stats_large_{n_big}.csv: `rocprofv3 --kernel-trace --stats -- python3 bench.py "
+                                            f"--only-large-n {n_big}` — this leg alone, one row of step_kernel_parts per size"}}
+
+    # ---- `--only-large-n N`: that leg alone (so that a rocprofv3 --kernel-trace --stats run of it has ONE size in its step_kernel_parts row)
+    if args.only_large_n:
+        if rank == 0 and world == 1:
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            pmc = json.load(open(pmc_path)) if os.path.exists(pmc_path) else {}
+            leg = large_leg(args.only_large_n, 5, 16 if args.only_large_n > 1000000 else 64, 7 if args.only_large_n > 1000000 else 9, 99, 2)
+            print(json.dumps({"metric": "env steps/sec", "leg": "only-large-n", **leg}), flush=True)
+        env.close()
+        if distributed:
+            dist.barrier(); dist.destroy_process_group()
+        return
+
     # ---- the same kernel family beyond the Infinity Cache: fused layout at 4,194,304 envs (N=1 only)
     if rank == 0 and world == 1 and not args.no_large_n:
         try:
-            n_big = 4194304
-            gen_b = torch.Generator(device=device).manual_seed(99)
-            acts_b = [(torch.rand((n_big, 6), device=device, generator=gen_b) * 2 - 1).contiguous() for _ in range(2)]
-            # three fresh allocations of the batch: beyond the cache the launch time depends on where the driver places the
-            # workspace (same virtual addresses and work: 289 or 345 us, tools/large_n_variance.py) — report the median, list all
-            trials = []
-            for _trial in range(3):
-                big = RendezvousBatch(n_big, device=device, storage=args.storage, seed=0)
-                big.reset()
-                for t in range(24):
-                    big.step(acts_b[t % 2])
-                trials.append(timed_steps(big, acts_b, 16, 7))
-                big.close(); del big
-                torch.cuda.empty_cache()
-            us_big = sorted(trials)[1]
-            ach = ALGO_BYTES_PER_ENV_STEP * n_big / (us_big * 1e-6) / 1e9
-            tr = pmc.get(f"{args.storage}_{n_big}")
-            out["large_n"] = {"value": n_big / (us_big * 1e-6), "unit": "env steps/s", "envs": n_big, "launch_us": us_big,
-                              "launch_us_per_allocation": trials,
-                              "kernel": "rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>"),
-                              "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBPS,
-                                           "traffic": tr["bytes_per_launch"] if tr else None,
-                                           "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" if tr else None},
-                              "note": "1.2 GB of state + I/O per launch: HBM, not Infinity Cache; value = the median of three fresh allocations "
-                                      "of the batch, each after 0.1 s of sustained load (launch_us_per_allocation: it has two modes, by box and moment, most plausibly "
-                                      "the clocks the socket sustains at its power limit: DESIGN.md section 5)"}
-            del acts_b
-            torch.cuda.empty_cache()
+            out["large_n"] = large_leg(4194304, 5, 16, 7, 99, 2)
+            out["large_n"]["note"] = ("1.2 GB of state + I/O per launch: HBM, not Infinity Cache; value / launch_us / frac = the MEDIAN of five fresh "
+                                      "allocations of the batch, each after 0.1 s of sustained load; min and max beside it (launch_us_min_median_max, "
+                                      "frac_at_min_median_max_launch_us): the launch time has modes by box and moment, most plausibly the clocks the "
+                                      "socket sustains at its power limit (DESIGN.md section 5)")
         except Exception as exc:  # pragma: no cover
             out["large_n"] = {"error": repr(exc)}
 
     # ---- informational: BASELINE config 4's GLOBAL batch (524,288 envs = 8 shards of 65,536) stepped by ONE GPU (fused kernel)
     if rank == 0 and world == 1 and not args.no_large_n:
         try:
-            n_mid = 524288
-            gen_m = torch.Generator(device=device).manual_seed(77)
-            acts_m = [(torch.rand((n_mid, 6), device=device, generator=gen_m) * 2 - 1).contiguous() for _ in range(4)]
-            mid = RendezvousBatch(n_mid, device=device, storage=args.storage, seed=0)
-            mid.reset()
-            for t in range(24):
-                mid.step(acts_m[t % 4])
-            us_mid = timed_steps(mid, acts_m, 64, 9)
-            ach_m = ALGO_BYTES_PER_ENV_STEP * n_mid / (us_mid * 1e-6) / 1e9
-            tr_m = pmc.get(f"{args.storage}_{n_mid}")
-            out["config4_global_batch_on_one_gpu"] = {"value": n_mid / (us_mid * 1e-6), "unit": "env steps/s", "envs": n_mid, "launch_us": us_mid,
-                                                      "kernel": "rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>"),
-                                                      "roofline": {"bound": "hbm", "achieved": ach_m, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                                                   "frac": ach_m / HBM_PEAK_GBPS, "traffic": tr_m["bytes_per_launch"] if tr_m else None,
-                                                                   "traffic_source": "profiles/pmc_traffic.json (separate rocprofv3 --pmc passes, not this run)" if tr_m else None},
-                                                      "note": "154 MB of state + I/O per launch: within the 256 MiB Infinity Cache"}
-            mid.close(); del mid, acts_m
-            torch.cuda.empty_cache()
+            out["config4_global_batch_on_one_gpu"] = large_leg(524288, 5, 64, 9, 77, 4)
+            out["config4_global_batch_on_one_gpu"]["note"] = "154 MB of state + I/O per launch: within the 256 MiB Infinity Cache; median of five fresh allocations"
         except Exception as exc:  # pragma: no cover
             out["config4_global_batch_on_one_gpu"] = {"error": repr(exc)}
 

@@ -120,19 +120,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
 #endif
     StepResult r;
     const RowSink my_row{wl + lane * RDV_OBS_DIM};      // the observation is staged as it is formed
+    constexpr bool kPack = sizeof(ST) == 4;   // (see step_kernel_split)
     V packed[kChunks];
-    const bool stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row, NoHook(), packed);
+    const bool stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row, NoHook(), kPack ? packed : nullptr);
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
     store_step_outputs<true>(Aw, lane, active, fin, r, e, my_row.row);
     const bool to_reset = fin && resets;
-    if (fin && A.on_done == RDV_ON_DONE_HALT) { e.flags |= FLAG_HALTED; packed[5].z = u2s(e.flags, ST(0)); }
+    if (fin && A.on_done == RDV_ON_DONE_HALT) { e.flags |= FLAG_HALTED; if (kPack) packed[5].z = u2s(e.flags, ST(0)); }
     if (resets) {
       job_kind[threadIdx.x] = to_reset ? JOB_REFILL : JOB_NONE;
       job_counter[threadIdx.x] = e.episode;
     }
-    if (stepped && !to_reset) store_chunks<ST>(wsw, A.cs, lane, packed, false);   // a listed env's state is written by the parts, all seven chunks
+    if (stepped && !to_reset) { if (kPack) store_chunks<ST>(wsw, A.cs, lane, packed, false); else store_env<ST>(wsw, A.cs, lane, e, false); }   // a listed env's state is written by the parts, all seven chunks
   }
   RDV_STAMP(3);
   if (resets) {
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     // one is stored (one wave per SIMD here: the 17 registers cost no occupancy).
     float obs_r[RDV_OBS_DIM];
     float* my_row = wl + lane * RDV_OBS_DIM;
-    V packed[kChunks];
-    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; }, NoHook(), packed);
+    constexpr bool kPack = sizeof(ST) == 4;   // fp32 storage: pack inside the stepped branch (advance()); fp64 storage has nothing to convert — there the
+    V packed[kChunks];                        // 56 extra registers of a packed copy cost 0.4 us per launch (8.75 -> 9.17 measured), so it stores from `e`
+    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; }, NoHook(), kPack ? packed : nullptr);
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     const bool to_reset = fin && resets;
@@ -256,8 +258,8 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     // The state of the envs that go on is stored BEFORE the barrier (round 3): the step waves reach it ~700 cycles ahead of the service
     // waves, and these 6 x 16-byte-per-lane stores drain inside that wait instead of after it (tools/lib_ab.py: 6.80 -> 6.73 us at
     // 65,536 envs, 5.35 -> 5.29 at 16,384; moving the reward / done / terminal-row stores there as well loses: 6.89).  Reset lanes: service wave.
-    if (fin && A.on_done == RDV_ON_DONE_HALT) { e.flags |= FLAG_HALTED; packed[5].z = u2s(e.flags, ST(0)); }
-    if (stepped && !to_reset) store_chunks<ST>(ws, A.cs, i, packed, false);
+    if (fin && A.on_done == RDV_ON_DONE_HALT) { e.flags |= FLAG_HALTED; if (kPack) packed[5].z = u2s(e.flags, ST(0)); }
+    if (stepped && !to_reset) { if (kPack) store_chunks<ST>(ws, A.cs, i, packed, false); else store_env<ST>(ws, A.cs, i, e, false); }
     RDV_STAMP(3);
     __syncthreads();
     RDV_STAMP(4);

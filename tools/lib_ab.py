@@ -14,7 +14,7 @@ if sys.argv[1] != "-":
     _native.STRICT = False      # an older build may lack the newest entry points
 from reinforcement_learning_rendezvous_amd.batch import RendezvousBatch
 for n in [int(x) for x in os.environ.get("AB_SIZES", "65536,32768").split(",")]:
-    env = RendezvousBatch(n, device="cuda:0", storage="f32", seed=0)
+    env = RendezvousBatch(n, device="cuda:0", storage=os.environ.get("AB_STORAGE", "f32"), seed=0)
     g0 = torch.Generator(device="cuda:0").manual_seed(1)
     acts = [(torch.rand((n, 6), device="cuda:0", generator=g0) * 2 - 1).contiguous() for _ in range(16)]
     env.reset()

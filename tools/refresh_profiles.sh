@@ -2,6 +2,7 @@
 # Runs on the GPU box (gpurun -- 'bash tools/refresh_profiles.sh'): the measurements profiles/ is built from.
 #   1. bench.py (default flags, and the driver's --steps 20 --warmup 5)             -> gpurun_out/refresh/bench_*.json
 #   2. rocprofv3 --kernel-trace --stats of the default bench command                 -> gpurun_out/refresh/kstats/
+#      and of `bench.py --only-large-n N` for N = 524,288 and 4,194,304 (one size per run) -> gpurun_out/refresh/kstats_large_N/
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per workload        -> gpurun_out/refresh/pmc/<key>_<COUNTER>/
 # Counters are collected without any other trace domain (only --kernel-trace), the program after `--` is python3 itself.
 set -o pipefail
@@ -16,6 +17,11 @@ echo "bench driver flags done"
 cd /tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kstats" -o p -- python3 "$R/bench.py" > "$OUT/bench_profiled.json" 2> "$OUT/bench_profiled.err" || exit 1
 echo "kernel stats done"
+# one row of step_kernel_parts PER SIZE: the large-batch legs alone, each in its own traced run (bench.py --only-large-n)
+for N in 524288 4194304; do
+  timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kstats_large_$N" -o p -- python3 "$R/bench.py" --only-large-n $N > "$OUT/bench_large_$N.json" 2> "$OUT/bench_large_$N.err" || exit 1
+  echo "kernel stats, $N envs alone, done"
+done
 pmc() {   # key, script, args...
   local key=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
