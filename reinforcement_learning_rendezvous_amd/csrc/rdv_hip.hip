@@ -99,6 +99,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
   const bool resets = A.on_done == RDV_ON_DONE_RESET;   // kernel-uniform: the barriers below are executed by all waves or by none
   RDV_STAMP_DECL
   RDV_STAMP(0);
+  // Staggered start (round 4): a launch of a few rounds of workgroups runs in lockstep — every resident wave loads at once (a 35 MB
+  // burst), then all compute, then the next round loads at once — so the memory system idles while the SIMDs work and vice versa.
+  // The first-round workgroups (the first 4 per CU) therefore start `stagger` x 512 cycles apart by their slot on the CU; their
+  // successors inherit the phase.  Pure delay, no effect on results; sized by kStagger* below (profiles/r04_stagger.txt).
+  if (A.stagger && blockIdx.x < 1024u) {
+    const int slot = (int)(blockIdx.x >> 8);             // the k-th workgroup of its CU (256 CUs, dealt round-robin)
+    for (int k = 0; k < slot * A.stagger; ++k) __builtin_amdgcn_s_sleep(8);   // 512 cycles each
+  }
 
   {
     V* wsw = ws + wave_base;                             // this wave's slice of every chunk array: chunk c of lane l at wsw[c * cs + l]
@@ -1191,6 +1199,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   } else {
     dim3 grid = grid_for(h->n), block(kBlock);
     A.stream_rows = h->n <= kStreamRowsMaxEnvs ? 1 : 0;
+    { static const int forced = [] { const char* x = getenv("RDV_STAGGER"); return x ? atoi(x) : -1; }();     // diagnostics: units of 512 cycles
+      A.stagger = forced >= 0 ? forced : stagger_by_size(h->n); }
     if (h->xcd_order == 1 || (h->xcd_order < 0 && xcd_order_by_size(h->n))) {
       A.xcd_per = (int32_t)((grid.x + 7) / 8);
       grid = dim3((unsigned)A.xcd_per * 8u);   // up to 7 padding workgroups, which find no envs

@@ -34,6 +34,11 @@ static inline bool xcd_order_by_size(int64_t n) { return n <= kXcdOrderMaxEnvs &
 // 22.57 -> 21.24, 327,680 26.98 -> 26.57, 393,216 30.9 -> 30.1; 458,752 and 524,288 +-2 % either way, 786,432 57.7 -> 61.6 (worse).
 constexpr int64_t kStreamRowsMaxEnvs = 393216;
 constexpr int kTilesPerCU = 3;                  // RDV_VARIANT_FUSED_TILES: workgroups per CU (three waves per SIMD at <= 168 registers)
+// step_kernel_parts: start-up stagger of the first-round workgroups in units of 512 cycles per CU slot, by batch size (tools/lib_ab_large.py on one
+// box, alternating processes, us per launch without | with; profiles/r04_stagger.txt): 196,608 envs 12.9 | 13.3 (6 units: worse), 262,144 17.5 | 16.4 (6),
+// 393,216 26.9 | 24.8 (8), 524,288 33.8 | 31.1 (8), 786,432 and 1,048,576: within the noise (4), 4,194,304: none at any value — sixteen rounds fall out of
+// step by themselves.  On between 229,376 and 655,360 envs (one to two and a half rounds of four workgroups per CU).
+static inline int stagger_by_size(int64_t n) { return (n < 229376 || n >= 655360) ? 0 : n < 393216 ? 6 : 8; }
 constexpr int64_t kSplitAutoMaxEnvs = 65536;    // measured crossover (tools/n_sweep.py, profiles/r02_n_sweep_parts.csv): split wins up to one 256-env workgroup per CU
 enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
        ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
@@ -147,6 +152,7 @@ struct StepArgs {
   uint32_t* prep_tag;       // [N]
   int32_t xcd_per;          // fused kernels: workgroups per XCD region (0: plain block order)
   int32_t stream_rows;      // fused kernels: store the observation rows non-temporally (kStreamRowsMaxEnvs)
+  int32_t stagger;          // step_kernel_parts: first-round workgroups start k x 2,048 cycles apart by their slot on the CU (0: off)
 #ifdef RDV_STAMPS
   unsigned long long* stamps;
 #endif
