@@ -1,7 +1,8 @@
 """GPU tests (run with `-m gpu`) of the hand-written policy kernel (csrc/rdv_policy.h) against the PyTorch fp32 reference
 of the same op — the one floating-point kernel of the repo that has a torch reference (tolerance: 2e-6 absolute on actions
-in [-1, 1]: the kernel takes each product as the six leading terms of three-way bf16 splits — fp32-level, summed in another
-order — and uses a few-ulp tanh)."""
+in [-1, 1]: the kernel takes each product as the three leading terms of TWO-term fp16 splits of the power-of-two-scaled
+operands (x = hi + lo to 22 bits: fp32-level, summed in another order; 1.4e-6 from an fp64 evaluation where a plain fp32
+GEMM is 4.4e-6) and uses a few-ulp tanh)."""
 import os
 
 import numpy as np

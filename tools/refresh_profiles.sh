@@ -5,11 +5,14 @@
 #      and of `bench.py --only-large-n N` for N = 524,288 and 4,194,304 (one size per run) -> gpurun_out/refresh/kstats_large_N/
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, per workload        -> gpurun_out/refresh/pmc/<key>_<COUNTER>/
 # Counters are collected without any other trace domain (only --kernel-trace), the program after `--` is python3 itself.
+# Two parts (a gpurun call is limited to 20 minutes): `refresh_profiles.sh bench` = 1 + 2, `refresh_profiles.sh pmc` = 3; no argument = both.
 set -o pipefail
+PART=${1:-all}
 R=$(pwd)
 OUT=$R/gpurun_out/refresh
-rm -rf "$OUT"; mkdir -p "$OUT/pmc"
+mkdir -p "$OUT/pmc"
 export TMPDIR=/tmp
+if [ "$PART" = all ] || [ "$PART" = bench ]; then
 timeout -k 10 400 python3 bench.py > "$OUT/bench_default.json" 2> "$OUT/bench_default.err" || exit 1
 echo "bench default done"
 timeout -k 10 400 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_driver_flags.json" 2> "$OUT/bench_driver_flags.err" || exit 1
@@ -22,6 +25,10 @@ for N in 524288 4194304; do
   timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kstats_large_$N" -o p -- python3 "$R/bench.py" --only-large-n $N > "$OUT/bench_large_$N.json" 2> "$OUT/bench_large_$N.err" || exit 1
   echo "kernel stats, $N envs alone, done"
 done
+cd "$R"
+fi
+if [ "$PART" = all ] || [ "$PART" = pmc ]; then
+cd /tmp
 pmc() {   # key, script, args...
   local key=$1; shift
   for c in FETCH_SIZE WRITE_SIZE; do
@@ -38,5 +45,6 @@ pmc persist "$R/tools/persistent_once.py"
 for c in FETCH_SIZE WRITE_SIZE; do
   cp -r "$OUT/pmc/persist_$c" "$OUT/pmc/step_many_f32_65536_K64_$c" && mv "$OUT/pmc/persist_$c" "$OUT/pmc/rollout_f32_65536_T64_$c" || exit 1
 done
+fi
 find "$OUT" -name "*.csv" -size +20M -delete      # kernel traces of the long bench run are not needed, the stats are
-echo "refresh complete"
+echo "refresh $PART complete"
