@@ -179,8 +179,8 @@ def test_constructor_and_make_env_surface_reproduce_the_reference():
 
 
 def test_no_kernel_uses_scratch_and_the_fused_step_fits_four_waves_per_simd():
-    """Every kernel the library can launch keeps everything in registers: `make resource` (hipcc's kernel-resource remarks, gfx950
-    cross-compile, no GPU needed) must report ScratchSize 0 for ALL of them — the one-launch step kernels (general rigid bodies
+    """Every kernel the library can launch keeps everything in registers: `make resource` (hipcc's kernel-resource remarks for all three
+    translation units, gfx950 cross-compile, no GPU needed) must report ScratchSize 0 for ALL of them — the one-launch step kernels (general rigid bodies
     included), the actor / critic, the persistent kernels — and step_kernel_parts<float>, the kernel of batches beyond one workgroup
     per CU, must fit 128 vector registers (four waves per SIMD).  (The general rigid-body forms of rdv_step_many / rdv_rollout, which
     spilled in round 2, are no longer instantiated: those calls run the rdv_step loop, include/rdv.h.)"""
@@ -202,7 +202,8 @@ def test_no_kernel_uses_scratch_and_the_fused_step_fits_four_waves_per_simd():
             vgprs[name] = int(m.group(1))
     want = ["step_kernel_splitIf", "step_kernel_splitId", "step_kernel_partsIf", "step_kernel_partsId",
             "step_kernelIfLb0ELb0ELb0", "step_kernelIdLb0ELb0ELb0", "step_kernelIfLb0ELb1ELb0", "step_kernelIfLb1ELb1ELb0", "policy_act_kernel",
-            "policy_value_kernel", "rollout_kernelIfLb0", "rollout_kernelIdLb0", "step_many_kernelIfLb0", "step_many_kernelIdLb0"]
+            "policy_value_kernel", "rollout_kernelIfLb0", "rollout_kernelIdLb0", "step_many_kernelIfLb0", "step_many_kernelIdLb0",
+            "step_kernel_tilesIf", "step_kernel_tilesId", "step_kernel_generalIf", "step_kernel_generalId"]      # (round 4: rdv_tiles.hip, rdv_general.hip)
     for w in want:
         assert any(w in k for k in scratch), f"no kernel matching {w} in the resource report"
     assert len(scratch) >= 30
@@ -211,3 +212,6 @@ def test_no_kernel_uses_scratch_and_the_fused_step_fits_four_waves_per_simd():
     assert not any("rollout_kernelIfLb1" in k or "step_many_kernelIfLb1" in k for k in scratch)      # not instantiated any more
     parts = [v for k, v in vgprs.items() if "step_kernel_partsIf" in k]
     assert parts and max(parts) <= 128, parts
+    # the RK45 kernels fit two waves per SIMD (<= 256 registers, nothing parked in AGPRs or scratch) and the tile loop three (<= 168)
+    assert max(v for k, v in vgprs.items() if "step_kernel_general" in k or "step_kernelIfLb0ELb1" in k or "step_kernelIdLb0ELb1" in k) <= 256
+    assert max(v for k, v in vgprs.items() if "step_kernel_tilesIf" in k) <= 168
