@@ -797,10 +797,8 @@ __device__ __forceinline__ void step_target(const DevParams& P, double* qt, doub
 
 // Second half (:187-221): the target's state made canonical, its half of the derived quantities, the latches, bookkeeping, reward,
 // observation and termination.
-// `late()` is called behind derive_target, where the transition's register pressure has passed its peak (two rotation matrices are dead,
-// the reward and the observation are still to come): the tile loop issues its look-ahead fetch there (step_kernel_tiles).
-template <typename ST, bool kLazy, bool kGeneral = false, typename Sink, typename Hook = NoHook>
-__device__ __forceinline__ void step_env_finish(const DevParams& P, Env& e, StepResult& r, Derived& d, const StepCtx& c, Sink&& sink, Hook&& late = Hook()) {
+template <typename ST, bool kLazy, bool kGeneral = false, typename Sink>
+__device__ __forceinline__ void step_env_finish(const DevParams& P, Env& e, StepResult& r, Derived& d, const StepCtx& c, Sink&& sink) {
   const ST tag = ST(0);
   if (kGeneral) {
 #pragma unroll
@@ -809,7 +807,6 @@ __device__ __forceinline__ void step_env_finish(const DevParams& P, Env& e, Step
 #pragma unroll
   for (int i = 0; i < 4; ++i) e.qt[i] = canon(e.qt[i], tag);
   derive_target<kLazy>(P, e, d, c.inv_dist);
-  late();
   const bool inst_coll = in_koz(P, d);
   // :187-190
   if (!(e.flags & FLAG_COLLIDED)) {

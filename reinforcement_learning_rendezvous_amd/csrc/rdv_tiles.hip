@@ -65,9 +65,6 @@ __device__ __forceinline__ void tile_touch<double>(TileInputs<double>& in) {
 #ifndef RDV_TILES_WAVES
 #define RDV_TILES_WAVES 3
 #endif
-#ifndef RDV_TILES_LATE_FETCH
-#define RDV_TILES_LATE_FETCH 0
-#endif
 template <typename ST>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(ST) == 4 ? RDV_TILES_WAVES : 2))) void step_kernel_tiles(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                              uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
@@ -160,19 +157,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
       // region, hence ONE site for the look-ahead fetch: two sites (a second one for lanes that skip the transition) have the
       // compiler merge their registers with copies in the middle of the tile, each copy a wait for the fetch.
       Derived d;
-#if RDV_TILES_LATE_FETCH == 1
-      {
-        StepCtx c;
-        step_env_chaser<ST, false, false>(P, e, a, d, c);
-        step_target<false, false>(P, e.qt, e.wt);
-        step_env_finish<ST, true, false>(P, e, r, d, c, my_row, request_next);
-      }
-#elif RDV_TILES_LATE_FETCH == 2
-      step_env<ST, true, false, false>(P, e, a, r, d, my_row);
-      request_next();
-#else
       step_env<ST, true, false, false>(P, e, a, r, d, my_row, request_next);
-#endif
       TILE_PHASE(2);
       if (!active) {
         r.done = 0; r.reason = 0;
