@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak check (minutes, not part of the test suite): the three rdv_step layouts stepped side by side for tens of thousands of launches
+"""Soak check (minutes, not part of the test suite): the four rdv_step layouts stepped side by side for tens of thousands of launches
 with the same actions must stay bit-identical (state, bookkeeping, statistics), and the persistent kernels must keep agreeing with
 the step loop over thousands of steps.    python tools/soak.py [steps]"""
 import os, sys
@@ -11,8 +11,10 @@ from reinforcement_learning_rendezvous_amd.policy import MlpPolicy
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 30000
 dev = "cuda:0"
-for n, storage in ((65536, "f32"), (70000, "f64")):
-    envs = {v: RendezvousBatch(n, device=dev, storage=storage, seed=3, variant=v) for v in ("split", "fused", "fused_inlane")}
+for n, storage in ((65536, "f32"), (70000, "f64"), (524288 + 77, "f32")):      # the last: staggered start, XCD order off (ragged), three tiles per workgroup
+    if n > 500000:
+        steps = max(steps // 10, 1000)
+    envs = {v: RendezvousBatch(n, device=dev, storage=storage, seed=3, variant=v) for v in ("split", "fused", "fused_inlane", "fused_tiles")}
     g = torch.Generator(device=dev).manual_seed(5)
     ring = [(torch.rand((n, 6), device=dev, generator=g) * 2 - 1).contiguous() for _ in range(37)]
     ref = envs["split"]
@@ -32,7 +34,7 @@ for n, storage in ((65536, "f32"), (70000, "f64")):
                 assert torch.equal(ref.terminal_obs, e.terminal_obs) and torch.equal(ref.done_reason, e.done_reason), (v, t)
                 assert torch.equal(ref.get_state(), e.get_state()) and torch.equal(ref.get_aux(), e.get_aux()), (v, t)
                 assert ref.get_stats() == e.get_stats(), (v, t)
-            print(f"n={n} {storage}: {t + 1} steps, the three layouts agree; {ref.get_stats()['episodes']} episodes", flush=True)
+            print(f"n={n} {storage}: {t + 1} steps, the four layouts agree; {ref.get_stats()['episodes']} episodes", flush=True)
     for e in envs.values():
         e.close()
 
