@@ -271,8 +271,10 @@ __global__ __launch_bounds__(kPolBlock) void policy_act_kernel(const float* __re
   const int64_t nrows = (n - wave_base) < kPolWaveEnvs ? (n - wave_base) : kPolWaveEnvs;   // <= 0 for trailing waves of the last workgroup
 
   // ---- parameters -> LDS, once per workgroup (contiguous 16-byte-per-lane loads)
+#ifndef RDV_POL_NOSTAGE     // (diagnostic build: how long the staging takes — tools/policy_time.py with -DRDV_POL_NOSTAGE computes on whatever LDS holds)
   for (int q = threadIdx.x; q < kPolFloats / 4; q += kPolBlock)
     *reinterpret_cast<float4*>(w + 4 * q) = *reinterpret_cast<const float4*>(W + 4 * q);
+#endif
 
   // ---- observations [32,17] of this wave: contiguous loads -> plain LDS rows of stride 17 (missing rows = 0)
   if (nrows > 0) {
