@@ -44,17 +44,8 @@ __device__ __forceinline__ void tile_fetch(const StepArgs& A, int64_t wave_base,
 }
 
 // a use of every fetched register (empty asm): the compiler places its s_waitcnt for the fetch in front of it
-template <typename ST> __device__ __forceinline__ void tile_touch(TileInputs<ST>& in);
-template <>
-__device__ __forceinline__ void tile_touch<float>(TileInputs<float>& in) {
-#pragma unroll
-  for (int c = 0; c < kChunks; ++c) asm volatile("" : "+v"(in.c[c].x), "+v"(in.c[c].y), "+v"(in.c[c].z), "+v"(in.c[c].w));
-#pragma unroll
-  for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(in.a[k].x), "+v"(in.a[k].y));
-  asm volatile("" : "+v"(in.slot_pre));
-}
-template <>
-__device__ __forceinline__ void tile_touch<double>(TileInputs<double>& in) {
+template <typename ST>
+__device__ __forceinline__ void tile_touch(TileInputs<ST>& in) {
 #pragma unroll
   for (int c = 0; c < kChunks; ++c) asm volatile("" : "+v"(in.c[c].x), "+v"(in.c[c].y), "+v"(in.c[c].z), "+v"(in.c[c].w));
 #pragma unroll
