@@ -2,7 +2,9 @@
 // Its own translation unit because it is compiled with -mllvm -disable-machine-licm: with a loop around the transition, MachineLICM
 // hoists the ~50 fp64 literal materialisations (v_mov pairs) out of it, the allocator then carries them across the whole body and,
 // on top of the 36 look-ahead registers, spills them to scratch (98 dwords per lane; 481 us per launch at 4.2 M envs against 337).
-// Without the pass: 148 VGPRs, no scratch.
+// Without the pass: 152 VGPRs, no scratch.
+// An opt-in layout (RDV_VARIANT_FUSED_TILES), never chosen by AUTO: measured 3-8 % slower than step_kernel_parts at every size — the look-ahead
+// removes the wait for a tile's inputs and every other phase of the tile grows by as much (profiles/r04_tiles_stamps_and_ab.txt).
 #include "rdv_kernels.h"
 #include "rdv_slots.h"
 #include "rdv_tiles.h"
@@ -12,7 +14,7 @@ namespace rdv {
 // ---------------------------------------------------------------------------------------------------------------
 // step_kernel_parts as a TILE LOOP (round 4): a grid of about three workgroups per CU, each walking its XCD's contiguous tiles of
 // 256 envs, with the NEXT tile's inputs (seven 16-byte state chunks, the action row, the statistics slot) requested into registers
-// before the current tile's transition starts.  In the one-tile-per-workgroup kernel a wave issues its loads at entry and waits:
+// while the current tile computes (from inside its transition: see request_next below).  In the one-tile-per-workgroup kernel a wave issues its loads at entry and waits:
 // stamps at 4.2 M envs put 38 % of a wave's life there (profiles/r03_parts_stamps_and_prefetch.txt), and a CU's wave slots stand
 // empty between a workgroup's exit and its successor's arrival (~3,200 of 4,096 occupied).  Here the memory system always holds one
 // tile of requests per resident wave while that wave computes, and no slot turns over.  Per tile the work, its order and its
