@@ -565,9 +565,15 @@ __device__ __forceinline__ void philox4x32_10(uint32_t& c0, uint32_t& c1, uint32
 // ((field + 0.5) / 2^21 as ONE fma: field * 2^-21 + 2^-22 — every intermediate of either form is exact, so the same bits)
 __device__ __forceinline__ double u21(uint32_t field) { return fma((double)field, 1.0 / 2097152.0, 0.5 / 2097152.0); }
 
-// general.py:248-254: uniform(-1,1,3) normalised (cube-normalised direction, as the reference)
-__device__ __forceinline__ void unit_vector(double u0, double u1, double u2, double* o) {
-  const double v[3] = {fma(2.0, u0, -1.0), fma(2.0, u1, -1.0), fma(2.0, u2, -1.0)};
+// The same draw mapped onto (-1, 1): 2 u - 1 = field * 2^-20 + (2^-21 - 1) as ONE fma — exact like u21 and like fma(2, u21, -1): the same bits.
+// Eighteen of a reset's 24 uniforms are only ever used in that form (the three components of its six random directions).
+__device__ __forceinline__ double s21(uint32_t field) { return fma((double)field, 1.0 / 1048576.0, 1.0 / 2097152.0 - 1.0); }
+// which of the 24 uniforms of a reset are direction components (u[0..2] rc, u[4..6] vc, u[9..11] qc axis, u[12..14] wc, u[17..19] qt axis, u[20..22] wt)
+constexpr uint32_t kSignedUniforms = (7u << 0) | (7u << 4) | (7u << 9) | (7u << 12) | (7u << 17) | (7u << 20);
+
+// general.py:248-254: uniform(-1,1,3) normalised (cube-normalised direction, as the reference); v = the three draws already on (-1, 1)
+__device__ __forceinline__ void unit_vector(double v0, double v1, double v2, double* o) {
+  const double v[3] = {v0, v1, v2};
   const double inv = rsqrt64(dot3(v, v));
   o[0] = v[0] * inv; o[1] = v[1] * inv; o[2] = v[2] * inv;
 }
@@ -590,12 +596,15 @@ __device__ __forceinline__ void deviate(const double* axis, double theta, const 
   o[3] = fma(a[0], b[3], fma(b[0], a[3], fma(a[1], b[2], -a[2] * b[1])));
 }
 
-// One Philox block of the reset stream -> its six 21-bit uniforms u[6j .. 6j+5]
+// One Philox block of the reset stream -> its six 21-bit uniforms u[6j .. 6j+5], each in the form its one user wants: on (-1, 1) for the
+// direction components (kSignedUniforms), on (0, 1) for the magnitudes and angles
 __device__ __forceinline__ void reset_uniforms(uint64_t seed, uint64_t env_id, uint32_t episode, uint32_t j, double* u) {
   uint32_t c0 = (uint32_t)env_id, c1 = (uint32_t)(env_id >> 32), c2 = episode, c3 = j;
   philox4x32_10(c0, c1, c2, c3, (uint32_t)seed, (uint32_t)(seed >> 32));
-  u[6 * j + 0] = u21(c0 & 0x1FFFFFu); u[6 * j + 1] = u21(((c0 >> 21) | (c1 << 11)) & 0x1FFFFFu); u[6 * j + 2] = u21((c1 >> 10) & 0x1FFFFFu);
-  u[6 * j + 3] = u21(c2 & 0x1FFFFFu); u[6 * j + 4] = u21(((c2 >> 21) | (c3 << 11)) & 0x1FFFFFu); u[6 * j + 5] = u21((c3 >> 10) & 0x1FFFFFu);
+  const uint32_t f[6] = {c0 & 0x1FFFFFu, ((c0 >> 21) | (c1 << 11)) & 0x1FFFFFu, (c1 >> 10) & 0x1FFFFFu,
+                         c2 & 0x1FFFFFu, ((c2 >> 21) | (c3 << 11)) & 0x1FFFFFu, (c3 >> 10) & 0x1FFFFFu};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) u[6 * j + k] = ((kSignedUniforms >> (6 * j + k)) & 1u) ? s21(f[k]) : u21(f[k]);   // (j is a literal at every call site)
 }
 
 // Which part of a new initial state a call computes.  The six sampled quantities of reset() are independent given their
@@ -606,7 +615,10 @@ enum ResetPart : int { RESET_ALL = -1, RESET_RC_VC = 0, RESET_QC_WC = 1, RESET_Q
 
 // reset (:223-262): the new state (the fields of kPart; the others are left untouched) from (seed, env id, e.episode) or from a
 // tape row.  Draw order is the reference's: unit vector then magnitude for rc, vc, wc, wt; angle then axis for qc, qt.
-template <typename ST, int kPart>
+// kCanonAll = false (the split kernel's service waves, which compute every env's next state speculatively): only rc is rounded to the
+// storage type here — what the flags test below needs; the other 17 values are rounded where a finished env actually takes the state
+// (canon_rest), which is the same rounding applied later: 34 conversions less in front of the kernel's barrier for ~95 % of the lanes.
+template <typename ST, int kPart, bool kCanonAll = true>
 __device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
   constexpr bool all = kPart == RESET_ALL;
   constexpr bool do_rv = all || kPart == RESET_RC_VC, do_c = all || kPart == RESET_QC_WC, do_qt = all || kPart == RESET_QT || kPart == RESET_WT,
@@ -674,7 +686,12 @@ __device__ __forceinline__ void reset_fields(const DevParams& P, Env& e, uint64_
   const ST tag = ST(0);
   if (do_rv) {
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { e.rc[i] = canon(e.rc[i], tag); e.vc[i] = canon(e.vc[i], tag); }
+    for (int i = 0; i < 3; ++i) e.rc[i] = canon(e.rc[i], tag);
+  }
+  if (!kCanonAll) return;
+  if (do_rv) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) e.vc[i] = canon(e.vc[i], tag);
   }
   if (do_c) {
 #pragma unroll
@@ -704,11 +721,24 @@ __device__ __forceinline__ uint32_t reset_flags(const DevParams& P, const Env& e
   return (coll ? FLAG_COLLIDED : 0u) | ((succ ? 1u : 0u) << SUCCESS_SHIFT);
 }
 
+// the rounding reset_fields<.., kCanonAll = false> left out (everything but rc)
 template <typename ST>
+__device__ __forceinline__ void canon_rest(Env& e) {
+  const ST tag = ST(0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { e.vc[i] = canon(e.vc[i], tag); e.wc[i] = canon(e.wc[i], tag); e.wt[i] = canon(e.wt[i], tag); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { e.qc[i] = canon(e.qc[i], tag); e.qt[i] = canon(e.qt[i], tag); }
+}
+
+template <typename ST, bool kCanonAll = true>
 __device__ __forceinline__ void reset_state(const DevParams& P, Env& e, uint64_t seed, uint64_t env_id, const double* tape_row) {
-  reset_fields<ST, RESET_ALL>(P, e, seed, env_id, tape_row);
+  reset_fields<ST, RESET_ALL, kCanonAll>(P, e, seed, env_id, tape_row);
   e.flags = 0u;
-  if (reset_flags_needed(P, e)) e.flags = reset_flags(P, e);
+  if (reset_flags_needed(P, e)) {            // (never with the reference's nominal start 10 m out)
+    if (!kCanonAll) canon_rest<ST>(e);       // the flags are a function of the stored state (idempotent: the taker rounds again)
+    e.flags = reset_flags(P, e);
+  }
 }
 
 // the bookkeeping half of reset (:263-266)

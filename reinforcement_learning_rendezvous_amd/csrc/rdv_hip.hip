@@ -290,7 +290,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       RDV_STAMP(1);
       const double* row = nullptr;
       if (A.tape_depth > 0) row = A.tape + ((int64_t)(ne.episode % (uint32_t)A.tape_depth) * n + i) * RDV_STATE_DIM;
-      reset_state<ST>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);
+      reset_state<ST, false>(P, ne, A.seed, A.env_id_offset + (uint64_t)i, row);   // rounded to the storage type below, where a state is taken
       reset_aux<ST>(P, ne);
       RDV_STAMP(2);
     }
@@ -302,6 +302,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
       float* wl = stage + (wv - kSplitEnvs / kWave) * (kWave * RDV_OBS_DIM);
       if (active && ((m_reset >> lane) & 1ull)) {
         float robs[RDV_OBS_DIM];
+        canon_rest<ST>(ne);
         observation(P, ne, robs);
         store_env<ST>(ws, A.cs, i, ne, true);
 #pragma unroll
