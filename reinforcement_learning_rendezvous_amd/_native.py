@@ -81,9 +81,10 @@ class RigidBody(C.Structure):
 
 
 def build(force=False, quiet=True):
-    """Compile csrc/rdv_hip.hip for gfx950 into librdv_hip.so (hipcc cross-compiles without a GPU).  `make` owns the dependency
-    list (every header of csrc/ and include/rdv.h): it is always asked, and rebuilds only what is out of date."""
-    cmd = ["make", "-C", CSRC] + (["-B"] if force else [])
+    """Compile the three translation units of csrc/ (rdv_hip.hip, rdv_tiles.hip, rdv_general.hip) for gfx950 and link librdv_hip.so
+    (hipcc cross-compiles without a GPU).  `make` owns the dependency list (every header of csrc/ and include/rdv.h): it is always
+    asked, and rebuilds only what is out of date."""
+    cmd = ["make", "-C", CSRC, "-j3"] + (["-B"] if force else [])
     subprocess.check_call(cmd, stdout=subprocess.DEVNULL if quiet else None)
     return LIB_PATH
 
