@@ -299,7 +299,9 @@ __global__ __launch_bounds__(kPolBlock) void policy_act_kernel(const float* __re
 
   const int r = lane & 31, h = lane >> 5;
   float a[4];
+  if (wv < 4) __builtin_amdgcn_s_setprio(1);   // one of the SIMD's two waves strictly first through the layers (see rollout_kernel's phase A)
   actor_means(w, rows, lane, a);
+  if (wv < 4) __builtin_amdgcn_s_setprio(0);
   const float logp = actor_sample(w, lane, deterministic, seed, env_id_offset + (uint64_t)(wave_base + r), counter, a);
   if (log_prob && h == 0 && r < nrows) log_prob[wave_base + r] = logp;
   if (raw_actions && r < nrows) {      // kernel-uniform pointer test; the unclipped sample, written per lane (this form is not the hot one)

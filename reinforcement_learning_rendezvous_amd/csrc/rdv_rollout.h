@@ -216,7 +216,14 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       }
       const int er = ln & 31, eh = ln >> 5;
       float a[4];
+      // The SIMD's two actor waves run the same instruction stream side by side; left at equal priority they interleave and the later one
+      // reaches the barrier ~2,700 cycles after the earlier one.  With one of them (the older, a_wave < 4) strictly first through the three
+      // layers the other fills its issue gaps instead: 7.71 -> 7.30 us per closed-loop step (profiles/r04_actor_priority.txt; raising it
+      // over the sampling and the stores as well, or in parts of the layers only, is slower).
+      const bool first = a_wave < kGroupWaves;
+      if (first) __builtin_amdgcn_s_setprio(1);
       actor_means(w, xin, ln, a);
+      if (first) __builtin_amdgcn_s_setprio(0);
       float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (!A.deterministic) {
         if (eh == 0) {
