@@ -16,7 +16,7 @@ class ArenaBatch(RendezvousBatch):
         nbytes = int(torch.tensor([], dtype=dtype).element_size())
         for d in shape: nbytes *= d
         off = ArenaBatch.used
-        ArenaBatch.used = (off + nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+        ArenaBatch.used = (off + nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20) + int(os.environ.get("ARENA_SKEW", "0"))
         t = ArenaBatch.arena[off:off + nbytes].view(dtype).view(shape)
         t.zero_()
         return t
