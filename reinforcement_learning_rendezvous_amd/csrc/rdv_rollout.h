@@ -321,12 +321,10 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       __builtin_amdgcn_sched_barrier(0); te2 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0);
 #endif
       const bool fin = stepped && r.done;
-      if (active) {
-        A.reward[(int64_t)t * n + it] = r.reward;
-        A.done[(int64_t)t * n + it] = (uint8_t)r.done;
-      }
-      // episode statistics: the same wavefront reduction as rdv_step (same order of the fp64 sums), into the wave's LDS slot
-      stats_update(my_stats, ln < 12 ? my_stats[ln] : 0ull, ln, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+      // what the episode statistics need of the episode that may end here (a finished env takes its next state below)
+      const uint32_t st_flags = e.flags;
+      const int st_k = e.k;
+      const double st_ret = e.ep_ret, st_dv = e.sum_dv, st_dw = e.sum_dw;
       if (resets) {
         // every slot listed in an earlier step has been refilled, and the refilling waves are done reading the job arrays: four
         // signals per step (they were given ~2,300 cycles ago).  The wait is BOUNDED so that a lost signal cannot hang the launch
@@ -359,13 +357,23 @@ __global__ __launch_bounds__(kRollBlock) void rollout_kernel(const DevParams* __
       }
 #pragma unroll
       for (int j = 0; j < RDV_OBS_DIM; ++j) my_row[j] = obs_r[j];
-    }
-    ROLL_T(te3);
-    __syncthreads();   // observations of step t+1 are in LDS
-    ROLL_T(te4);
+      ROLL_T(te3);
+      __syncthreads();   // observations of step t+1 are in LDS
+      ROLL_T(te4);
 #ifdef RDV_STAMPS
-    acc_w1 += te1 - te0; acc_tr += te2 - te1; acc_tail += te3 - te2; acc_w2 += te4 - te3;
+      acc_w1 += te1 - te0; acc_tr += te2 - te1; acc_tail += te3 - te2; acc_w2 += te4 - te3;
 #endif
+      // Behind the barrier, beside the actor phase (where these waves would only wait), at the lowest priority: the reward / done rows
+      // and the episode statistics — the same wavefront reduction as rdv_step (same order of the fp64 sums), into the wave's LDS slot.
+      // In front of the barrier they were ~700 cycles of every step's critical path (profiles/r04_actor_priority.txt).
+      __builtin_amdgcn_s_setprio(0);
+      if (active) {
+        A.reward[(int64_t)t * n + it] = r.reward;
+        A.done[(int64_t)t * n + it] = (uint8_t)r.done;
+      }
+      stats_update(my_stats, ln < 12 ? my_stats[ln] : 0ull, ln, stepped, fin, r.reason, st_flags, st_k, st_ret, st_dv, st_dw);
+      __builtin_amdgcn_s_setprio(2);
+    }
    }
 #ifdef RDV_STAMPS
    if (A.stamps && lane == 0) {
