@@ -46,7 +46,7 @@ def main():
                        "coalesced read stream (x2 applied); WRITE_SIZE is exact for 16-B-per-lane stores",
                "command": "rocprofv3 --pmc <FETCH_SIZE|WRITE_SIZE> --kernel-trace --output-format csv -- python3 tools/step_once.py | persistent_once.py "
                           "(two separate passes; mean over the dispatches after the first two)",
-               "collected": datetime.date.today().isoformat(), "round": 3}
+               "collected": datetime.date.today().isoformat(), "round": 4}
         out[key] = rec
         print(key, name, f"{rec['bytes_per_launch'] / 1e6:.2f} MB per launch, {rec['bytes_per_env_step']:.1f} B per env-step")
     json.dump(out, open(out_path, "w"), indent=1)
