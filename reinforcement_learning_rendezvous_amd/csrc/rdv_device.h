@@ -768,7 +768,10 @@ struct StepResult {   // (the observation goes to the caller's sink: see observa
 // `mid()` is called once the chaser side is finished and the attitude error's table entry has been requested — the last load of a
 // transition: a kernel that fetches ahead (step_kernel_tiles) issues its look-ahead loads there, BEHIND that entry in the in-order
 // vector-memory counter, so that waiting for the entry does not mean waiting for the look-ahead.
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+  __device__ __forceinline__ void operator()(double&) const {}
+};
 
 // What the first half of a transition hands to the second (step_env = step_env_chaser + step_target + step_env_finish).
 struct StepCtx {
@@ -780,15 +783,18 @@ struct StepCtx {
 // of the derived quantities.  kGeneral: a body whose inertia tensor / torque is not the reference's (rdv_set_rigid_body) is integrated
 // with the reference's own scheme (RK45, both its attitude and its rate evolve) — PER BODY (P.body_general[0 | 1], wave-uniform): a
 // tumbling tri-axial target beside the reference's chaser leaves the chaser on the closed form.
-template <typename ST, bool kGeneral = false, bool kRaw = false>
-__device__ __forceinline__ void step_env_chaser(const DevParams& P, Env& e, const float* a, Derived& d, StepCtx& c) {
+// `pre()` is called once, behind the last thing that does not need the action (the chaser's rotation matrix) and in front of the first
+// use of `a`: a kernel whose action row is still in flight waits for it there (step_kernel_split / _parts: PinnedInputs).
+template <typename ST, bool kGeneral = false, bool kRaw = false, typename Pre = NoHook>
+__device__ __forceinline__ void step_env_chaser(const DevParams& P, Env& e, const float* a, Derived& d, StepCtx& c, Pre&& pre = Pre()) {
   const ST tag = ST(0);
-  // formed here, so that the six action registers die with the impulses below instead of living to the end of the transition
-  c.sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
-  c.sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
   // :172 delta_v = R(qc) * (a[0:3] * max_delta_v); the product is float32 (float32 array * Python float)
   double Rc0[9];
   quat2mat(e.qc, Rc0);
+  pre(Rc0[8]);   // (handed the matrix's last element: a wait written as inline assembly takes it as an operand, so it cannot be scheduled in front of the matrix)
+  // formed here, so that the six action registers die with the impulses below instead of living to the end of the transition
+  c.sum_v = (fabsf(a[0]) + fabsf(a[1])) + fabsf(a[2]);
+  c.sum_w = (fabsf(a[3]) + fabsf(a[4])) + fabsf(a[5]);
   const double dvb[3] = {(double)mul_f32_rn(a[0], P.max_delta_v_f32), (double)mul_f32_rn(a[1], P.max_delta_v_f32),
                          (double)mul_f32_rn(a[2], P.max_delta_v_f32)};
   double dv_l[3];
@@ -879,10 +885,11 @@ __device__ __forceinline__ void step_env_finish(const DevParams& P, Env& e, Step
 }
 
 // step (:160-221) on one env; `a` are the raw float32 actions (not clipped, as the reference :170).
-template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink, typename Hook = NoHook>
-__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink, Hook&& mid = Hook()) {
+template <typename ST, bool kLazy, bool kGeneral = false, bool kRaw = false, typename Sink, typename Hook = NoHook, typename Pre = NoHook>
+__device__ __forceinline__ void step_env(const DevParams& P, Env& e, const float* a, StepResult& r, Derived& d, Sink&& sink, Hook&& mid = Hook(),
+                                         Pre&& pre = Pre()) {
   StepCtx c;
-  step_env_chaser<ST, kGeneral, kRaw>(P, e, a, d, c);
+  step_env_chaser<ST, kGeneral, kRaw>(P, e, a, d, c, pre);
   mid();
   step_target<kGeneral, kRaw>(P, e.qt, e.wt);      // :184
   step_env_finish<ST, kLazy, kGeneral>(P, e, r, d, c, sink);

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void prepare_kernel(const DevParams* __rest
 // whole resets to the workgroup's last wave (profiles/r02_n_sweep_compacted_reset.csv), which held a wave slot and the LDS for a
 // lone serial chain.  Same expressions on the same inputs: bit-identical results.  (Forced to 128 VGPRs for four waves per SIMD it
 // spills 16 dwords and loses: 342 against 315 us at 4.2 M envs.)
-template <typename ST>
+template <typename ST, bool kAll>   // kAll: on_done != HALT — every lane runs the transition (advance_all)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(ST) == 4 ? RDV_PARTS_WAVES : 3))) void step_kernel_parts(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                              uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   StepArgs A = A_rest;
@@ -117,20 +117,44 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
     Aw.episode_return = A.episode_return ? A.episode_return + wave_base : nullptr;
     Aw.episode_length = A.episode_length ? A.episode_length + wave_base : nullptr;
     Env e;
-    if (active) load_env<ST>(wsw, A.cs, lane, e);
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-    const uint64_t slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;   // (a padding workgroup of the XCD order has no envs)
+    uint64_t slot_pre;
     float a[RDV_ACT_DIM];
-    load_actions(A.actions + wave_base * RDV_ACT_DIM, 0, lane, active, a);
+    PinnedInputs pin;
+    if constexpr (kAll && sizeof(ST) == 4) {
+      pinned_fetch(A, wave_base, lane, pin);             // state chunks, action row, statistics slot: all requested together (rdv_kernels.h: PinnedInputs)
+      pinned_wait_state(pin);                            // (a padding workgroup of the XCD order has no envs: it reads the batch's last wave and uses nothing)
+      pinned_unpack(pin, e);
+    } else if constexpr (kAll) {
+      TileInputs<ST> in;
+      tile_fetch<ST>(A, wave_base, lane, in);
+      unpack_env<ST>(in.c, e);
+      slot_pre = in.slot_pre;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { a[2 * k] = in.a[k].x; a[2 * k + 1] = in.a[k].y; }
+    } else {
+      if (active) load_env<ST>(wsw, A.cs, lane, e);
+      slot_pre = rows > 0 ? stats_preload(slot, lane) : 0ull;   // (a padding workgroup of the XCD order has no envs)
+      load_actions(A.actions + wave_base * RDV_ACT_DIM, 0, lane, active, a);
+    }
 #ifdef RDV_STAMPS
-    asm volatile("" : : "v"(e.rc[0]), "v"(e.vc[1]), "v"(e.wc[2]), "v"(e.qc[0]), "v"(e.qt[0]), "v"(e.ep_ret), "v"(e.wt[2]), "v"(a[5]));   // (the stamped build waits for the inputs here)
+    asm volatile("" : : "v"(e.rc[0]), "v"(e.vc[1]), "v"(e.wc[2]), "v"(e.qc[0]), "v"(e.qt[0]), "v"(e.ep_ret), "v"(e.wt[2])));   // (the stamped build waits for the state here)
     RDV_STAMP(1);
 #endif
     StepResult r;
     const RowSink my_row{wl + lane * RDV_OBS_DIM};      // the observation is staged as it is formed
     constexpr bool kPack = sizeof(ST) == 4;   // (see step_kernel_split)
     V packed[kChunks];
-    const bool stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row, NoHook(), kPack ? packed : nullptr);
+    bool stepped;
+    auto actions_ready = [&](double& after) {
+      if constexpr (kAll && sizeof(ST) == 4) {
+        pinned_wait_rest(pin, after);
+        a[0] = pin.a4.x; a[1] = pin.a4.y; a[2] = pin.a4.z; a[3] = pin.a4.w; a[4] = pin.a2.x; a[5] = pin.a2.y;
+        slot_pre = ((uint64_t)__float_as_uint(pin.sp.y) << 32) | __float_as_uint(pin.sp.x);
+      }
+    };
+    if constexpr (kAll) { advance_all<ST>(P, e, a, r, my_row, kPack ? packed : nullptr, actions_ready); stepped = active; }
+    else stepped = advance<ST, false, false, false>(A, P, wave_base + lane, active, e, a, r, my_row, NoHook(), kPack ? packed : nullptr);
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     stats_update(slot, slot_pre, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
@@ -209,7 +233,7 @@ constexpr int kSplitBlock = 512;     // 8 waves
 //    The step waves' transition is no faster beside nearly idle service waves (it is a dependency chain through the chaser side, not
 //    an issue count: removing the whole target side from it gains 0.17 us), and the slot copy is work they did not have before
 //    (profiles/r03_split_slots_hint.txt).
-template <typename ST>
+template <typename ST, bool kAll>   // kAll: on_done != HALT — every lane of the step waves runs the transition (advance_all)
 __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, const float* actions_hot, const DevParams* __restrict__ Pp, int64_t n_hot,
                                                        uint64_t* stats_hot, float* obs_hot, float* reward_hot, const StepArgs A_rest) {
   // The seven arguments every wave needs first are top-level kernel parameters so that they can be preloaded into SGPRs
@@ -240,11 +264,31 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     float* wl = stage + wv * (kWave * RDV_OBS_DIM);
     Env e;
     StepResult r;
-    if (active) load_env<ST>(ws, A.cs, i, e);
     uint64_t* slot = A.stats + (uint64_t)(wave_base / kWave) * kStatWords;
-    const uint64_t slot_pre = stats_preload(slot, lane);
+    uint64_t slot_pre;
     float a[RDV_ACT_DIM];
-    load_actions(A.actions, wave_base, lane, active, a);
+    PinnedInputs pin;
+    if constexpr (kAll && sizeof(ST) == 4) {
+      // state chunks, action row and statistics slot requested together (rdv_kernels.h: PinnedInputs); the state is waited for here, the
+      // action row behind the chaser's rotation matrix (actions_ready)
+      pinned_fetch(A, wave_base, lane, pin);
+      pinned_wait_state(pin);
+      pinned_unpack(pin, e);
+    } else if constexpr (kAll) {
+      TileInputs<ST> in;
+      tile_fetch<ST>(A, wave_base, lane, in);
+      unpack_env<ST>(in.c, e);
+      slot_pre = in.slot_pre;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { a[2 * k] = in.a[k].x; a[2 * k + 1] = in.a[k].y; }
+    } else {
+      if (active) load_env<ST>(ws, A.cs, i, e);
+      slot_pre = stats_preload(slot, lane);
+      load_actions(A.actions, wave_base, lane, active, a);
+    }
+#ifdef RDV_STAMPS
+    asm volatile("" : : "v"(e.rc[0]), "v"(e.vc[1]), "v"(e.wc[2]), "v"(e.qc[0]), "v"(e.qt[0]), "v"(e.ep_ret), "v"(e.wt[2]));   // (the stamped build waits for the state here)
+#endif
     RDV_STAMP(1);
     // observation rows: own row -> LDS as it is formed (stride 17: conflict-free) -> contiguous stores.  If an env of this wave
     // resets, the rows stay in LDS: the service wave swaps in the reset observation and stores the block — which is why this kernel
@@ -254,7 +298,17 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     float* my_row = wl + lane * RDV_OBS_DIM;
     constexpr bool kPack = sizeof(ST) == 4;   // fp32 storage: pack inside the stepped branch (advance()); fp64 storage has nothing to convert — there the
     V packed[kChunks];                        // 56 extra registers of a packed copy cost 0.4 us per launch (8.75 -> 9.17 measured), so it stores from `e`
-    const bool stepped = advance<ST, false>(A, P, i, active, e, a, r, [&](int j, float v) { obs_r[j] = v; my_row[j] = v; }, NoHook(), kPack ? packed : nullptr);
+    auto row_sink = [&](int j, float v) { obs_r[j] = v; my_row[j] = v; };
+    bool stepped;
+    auto actions_ready = [&](double& after) {
+      if constexpr (kAll && sizeof(ST) == 4) {
+        pinned_wait_rest(pin, after);
+        a[0] = pin.a4.x; a[1] = pin.a4.y; a[2] = pin.a4.z; a[3] = pin.a4.w; a[4] = pin.a2.x; a[5] = pin.a2.y;
+        slot_pre = ((uint64_t)__float_as_uint(pin.sp.y) << 32) | __float_as_uint(pin.sp.x);
+      }
+    };
+    if constexpr (kAll) { advance_all<ST>(P, e, a, r, row_sink, kPack ? packed : nullptr, actions_ready); stepped = active; }
+    else stepped = advance<ST, false>(A, P, i, active, e, a, r, row_sink, NoHook(), kPack ? packed : nullptr);
     RDV_STAMP(2);
     const bool fin = stepped && r.done;
     const bool to_reset = fin && resets;
@@ -1196,7 +1250,9 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
   if (split) {
     const dim3 grid((unsigned)((h->n + kSplitEnvs - 1) / kSplitEnvs));
     const dim3 block(kSplitBlock);
-    if (f32) RDV_LAUNCH(step_kernel_split<float>, grid, block); else RDV_LAUNCH(step_kernel_split<double>, grid, block);
+    const bool all = h->on_done != RDV_ON_DONE_HALT;   // no halted envs: every lane runs the transition, the inputs travel together (advance_all)
+    if (f32) { if (all) RDV_LAUNCH((step_kernel_split<float, true>), grid, block); else RDV_LAUNCH((step_kernel_split<float, false>), grid, block); }
+    else { if (all) RDV_LAUNCH((step_kernel_split<double, true>), grid, block); else RDV_LAUNCH((step_kernel_split<double, false>), grid, block); }
   } else {
     dim3 grid = grid_for(h->n), block(kBlock);
     A.stream_rows = h->n <= kStreamRowsMaxEnvs ? 1 : 0;
@@ -1223,7 +1279,9 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
         grid = dim3(g);
         launch_step_tiles(f32, grid, s, h->dev_params, A);
       } else {
-        if (f32) RDV_LAUNCH(step_kernel_parts<float>, grid, block); else RDV_LAUNCH(step_kernel_parts<double>, grid, block);
+        const bool all = h->on_done != RDV_ON_DONE_HALT;   // (see the split branch)
+        if (f32) { if (all) RDV_LAUNCH((step_kernel_parts<float, true>), grid, block); else RDV_LAUNCH((step_kernel_parts<float, false>), grid, block); }
+        else { if (all) RDV_LAUNCH((step_kernel_parts<double, true>), grid, block); else RDV_LAUNCH((step_kernel_parts<double, false>), grid, block); }
       }
     } else {
       if (f32) { if (dg) RDV_LAUNCH((step_kernel<float, true>), grid, block); else RDV_LAUNCH((step_kernel<float, false>), grid, block); }

@@ -179,6 +179,35 @@ __device__ __forceinline__ void load_actions(const float* __restrict__ actions, 
   }
 }
 
+// The inputs of one wave's transition as RAW registers: 7 state chunks, the action row, the wave's statistics slot.
+template <typename ST>
+struct TileInputs {
+  typename Vec4<ST>::type c[kChunks];
+  float2 a[3];
+  uint64_t slot_pre;
+};
+// Every lane issues every load (the index is clamped into the batch instead of being tested): no load sits under a branch, so all of
+// them are in flight together and each consumer waits for its own data only (in-order vmcnt) — written as `if (active) load_env(...)`,
+// then the statistics slot, then `load_actions(..., active, ...)`, the compiler closed each exec-masked block with a wait for everything
+// in flight and the action row was REQUESTED only after the state had arrived: two memory latencies in a row at the head of every
+// wave (round 4: tools/ubench_l2_retention.hip, profiles/r04_input_latency.txt).  In the tile loop the same property lets the fetch of
+// the next tile stay in flight across a wait for an OLDER load.  A lane without an env reads some valid env's data and never uses it.
+template <typename ST>
+__device__ __forceinline__ void tile_fetch(const StepArgs& A, int64_t wave_base, int lane, TileInputs<ST>& in) {
+  using V = typename Vec4<ST>::type;
+  const int64_t wb = wave_base < A.n ? wave_base : ((A.n - 1) & ~(int64_t)(kWave - 1));   // scalar
+  const int64_t rows = A.n - wb;                                                            // >= 1
+  const int l = lane < rows ? lane : 0;
+  const V* wsw = reinterpret_cast<const V*>(A.ws) + wb;
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) in.c[c] = wsw[c * A.cs + l];
+  const float* row = A.actions + wb * RDV_ACT_DIM + l * RDV_ACT_DIM;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) in.a[k] = *reinterpret_cast<const float2*>(row + 2 * k);
+  in.slot_pre = (A.stats + (uint64_t)(wb / kWave) * kStatWords)[lane & (kStatWords - 1)];   // (stats_update reads lanes 0..11)
+}
+
+
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
 // observations [64,17] of one wave: staged rows in LDS -> contiguous 16-byte-per-lane global stores
 // (`aligned`: dst is 16-byte aligned — always for [N,17] rows of a 64-env wave, for row t of a [T,N,17] tape only if N % 4 == 0)
@@ -286,6 +315,61 @@ __device__ __forceinline__ void stats_update(uint64_t* __restrict__ slot, uint64
   } else if (lane == 0) {
     slot[ST_STEPS] = pre + __popcll(m_step);
   }
+}
+
+// The transition on EVERY lane, without the `active` / halted tests of advance(): for kernels launched with on_done != HALT (no env is
+// ever halted there).  The lanes of the batch's ragged tail compute on some valid env's data (tile_fetch) and store nothing.  With no
+// branch between the fetch and its uses the compiler cannot sink the loads into one (it does: behind `if (active)` they were issued one
+// latency after the other), so state, action row and statistics slot travel together.  Same expressions as advance(): same results.
+template <typename ST, class Sink, class Pre = NoHook>
+__device__ __forceinline__ void advance_all(const DevParams& P, Env& e, const float* a, StepResult& r, Sink&& sink, typename Vec4<ST>::type* packed,
+                                            Pre&& pre = Pre()) {
+  r.done = 0; r.reason = 0; r.reward = 0.0f; r.reward64 = 0.0;
+  Derived d;
+  step_env<ST, true, false, false>(P, e, a, r, d, sink, NoHook(), pre);
+  if (packed) pack_env<ST>(e, packed);
+}
+
+// fp32 storage: the ten requests of a wave's inputs as inline assembly, in THIS order — seven state chunks, the action row (16 + 8
+// bytes), the statistics slot — so that all are in flight together and the state's consumers do not wait for the action row, which
+// may come from further away (another kernel wrote it).  Written as C++ loads the compiler chose the order itself: it sank loads into
+// the first branch that uses them, and with no branch left it still scheduled the action row's loads behind the first waits for the
+// state (the two latencies in a row again).  The compiler does not track these loads, so the waits are written out too:
+//   pinned_wait_state: vmcnt(3) — everything but the three youngest requests has landed (in-order counter) = the seven chunks;
+//   pinned_wait_rest:  vmcnt(0) — action row and statistics slot (called from step_env_chaser's `pre` hook).
+// Both take the registers as read-write operands: every use the compiler sees is of the value BEHIND the wait.  Loads the compiler
+// issues itself in between (there are none: the parameters travel on the scalar side) could only make these waits longer, never too
+// short, and its own counts stay safe with younger requests of ours in flight — the counter is in order.
+typedef float pin_f4 __attribute__((ext_vector_type(4)));
+typedef float pin_f2 __attribute__((ext_vector_type(2)));
+struct PinnedInputs {
+  pin_f4 c[kChunks];
+  pin_f4 a4;
+  pin_f2 a2;
+  pin_f2 sp;
+};
+__device__ __forceinline__ void pinned_fetch(const StepArgs& A, int64_t wave_base, int lane, PinnedInputs& in) {
+  const int64_t wb = wave_base < A.n ? wave_base : ((A.n - 1) & ~(int64_t)(kWave - 1));   // as tile_fetch: every lane loads, from a valid env
+  const int64_t rows = A.n - wb;
+  const int l = lane < rows ? lane : 0;
+  const pin_f4* wsw = reinterpret_cast<const pin_f4*>(A.ws) + wb + l;
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(in.c[c]) : "v"(wsw + c * A.cs));
+  const float* row = A.actions + (wb + l) * RDV_ACT_DIM;
+  asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16" : "=&v"(in.a4), "=&v"(in.a2) : "v"(row));
+  const uint64_t* sp = A.stats + (uint64_t)(wb / kWave) * kStatWords + (lane & (kStatWords - 1));
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(in.sp) : "v"(sp));
+}
+__device__ __forceinline__ void pinned_wait_state(PinnedInputs& in) {
+  asm volatile("s_waitcnt vmcnt(3)" : "+v"(in.c[0]), "+v"(in.c[1]), "+v"(in.c[2]), "+v"(in.c[3]));
+  asm volatile("" : "+v"(in.c[4]), "+v"(in.c[5]), "+v"(in.c[6]));
+}
+__device__ __forceinline__ void pinned_wait_rest(PinnedInputs& in, double& after) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(in.a4), "+v"(in.a2), "+v"(in.sp), "+v"(after)); }
+__device__ __forceinline__ void pinned_unpack(const PinnedInputs& in, Env& e) {
+  float4 c[kChunks];
+#pragma unroll
+  for (int j = 0; j < kChunks; ++j) c[j] = make_float4(in.c[j].x, in.c[j].y, in.c[j].z, in.c[j].w);
+  unpack_env<float>(c, e);
 }
 
 // per-env outputs of a transition (coalesced 4-/1-byte stores; the sparse ones only where an episode ended).  `row`: the lane's

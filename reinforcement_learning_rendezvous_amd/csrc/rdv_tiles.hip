@@ -20,31 +20,6 @@ namespace rdv {
 // tile of requests per resident wave while that wave computes, and no slot turns over.  Per tile the work, its order and its
 // expressions are step_kernel_parts': bit-identical results (tests/test_gpu_slots.py, test_gpu_fullsize.py).  The price is 36
 // registers of look-ahead: three waves per SIMD (<= 168 VGPRs) instead of four.
-template <typename ST>
-struct TileInputs {
-  typename Vec4<ST>::type c[kChunks];
-  float2 a[3];
-  uint64_t slot_pre;
-};
-// Every lane issues every load, whatever the tile (the index is clamped into the batch instead of being tested): the number of
-// vector-memory operations of a fetch is then the same on every path, and the compiler's in-order vmcnt bookkeeping can wait for an
-// OLDER load (the attitude error's table entry) with the fetch still in flight — behind a branch it has to assume the shorter path
-// and waits for everything.  A lane without an env reads some valid env's data and never uses it.
-template <typename ST>
-__device__ __forceinline__ void tile_fetch(const StepArgs& A, int64_t wave_base, int lane, TileInputs<ST>& in) {
-  using V = typename Vec4<ST>::type;
-  const int64_t wb = wave_base < A.n ? wave_base : ((A.n - 1) & ~(int64_t)(kWave - 1));   // scalar
-  const int64_t rows = A.n - wb;                                                            // >= 1
-  const int l = lane < rows ? lane : 0;
-  const V* wsw = reinterpret_cast<const V*>(A.ws) + wb;
-#pragma unroll
-  for (int c = 0; c < kChunks; ++c) in.c[c] = wsw[c * A.cs + l];
-  const float* row = A.actions + wb * RDV_ACT_DIM + l * RDV_ACT_DIM;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) in.a[k] = *reinterpret_cast<const float2*>(row + 2 * k);
-  in.slot_pre = (A.stats + (uint64_t)(wb / kWave) * kStatWords)[lane & (kStatWords - 1)];   // (stats_update reads lanes 0..11)
-}
-
 // a use of every fetched register (empty asm): the compiler places its s_waitcnt for the fetch in front of it
 template <typename ST>
 __device__ __forceinline__ void tile_touch(TileInputs<ST>& in) {
