@@ -386,8 +386,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "achieved_from_traffic": (traffic / (launch_us * 1e-6) / 1e9) if traffic else None,
-                         "kernel": ("rdv::step_kernel_split" + ("<float>" if args.storage == "f32" else "<double>")) if n <= 65536 else
-                                   ("rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>")),
+                         "kernel": ("rdv::step_kernel_split" + ("<float, true>" if args.storage == "f32" else "<double, true>")) if n <= 65536 else
+                                   ("rdv::step_kernel_parts" + ("<float, true>" if args.storage == "f32" else "<double, true>")),
                          "launch_us": launch_us, "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
                          "note": "achieved = 293 B x envs per launch / launch_us.  At 65,536 envs the 15 MB working set stays in the 256 MiB "
                                  "Infinity Cache between launches (FETCH/WRITE_SIZE count fabric requests, MALL hits included): the HBM "
@@ -517,7 +517,7 @@ def main():
         tr = pmc.get(f"{args.storage}_{n_big}") if rank == 0 else None
         return {"value": n_big / (us["median"] * 1e-6), "unit": "env steps/s", "envs": n_big, "launch_us": us["median"],
                 "launch_us_min_median_max": [us["min"], us["median"], us["max"]], "launch_us_per_allocation": trials,
-                "kernel": "rdv::step_kernel_parts" + ("<float>" if args.storage == "f32" else "<double>"),
+                "kernel": "rdv::step_kernel_parts" + ("<float, true>" if args.storage == "f32" else "<double, true>"),
                 "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": frac["median"],
                              "frac_at_min_median_max_launch_us": [frac["min"], frac["median"], frac["max"]],
                              "traffic": tr["bytes_per_launch"] if tr else None,
