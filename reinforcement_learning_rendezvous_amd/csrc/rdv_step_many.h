@@ -10,7 +10,9 @@
 //     workgroup's 256 slots live in LDS for the duration of the launch;
 //   - waves 4-7 ("service waves", one per SIMD beside an env wave) refill the slots used in the previous step, sharing the work by
 //     PART (rc+vc | qc+wc | qt | wt) over the same compacted list: ~13 of 256 envs per step with random actions, a ~300-instruction
-//     stream per SIMD and step where round 1 ran the whole ~900-instruction reset for every lane.
+//     stream per SIMD and step where round 1 ran the whole ~900-instruction reset for every lane.  They also do the episode statistics
+//     of the previous step (round 4): the env wave hands the nine words per lane that stats_update reads over through LDS (6 writes)
+//     instead of running its ~190 instructions on the one chain that bounds the step; same function, same order of the sums.
 // Two workgroup barriers per step: A (refills of the previous step are in LDS; the transition of this step is done) and B (the
 // slots that were taken are listed).  At the end the slots that changed go back to HBM, clean.
 #pragma once
@@ -20,11 +22,12 @@ namespace rdv {
 constexpr int kManyEnvs = kGroupEnvs;         // 256
 constexpr int kManyEnvWaves = kManyEnvs / kWave;   // 4
 constexpr int kManyBlock = 2 * kManyEnvs;          // 512 threads: 4 env waves + 4 service waves
-// dynamic LDS: observation rows [256][17] | action rows [256][6] | job kind [256] | job counter [256] | 4 statistics slots |
+// dynamic LDS: observation rows [256][17] | statistics hand-over [9][256] words | job kind [256] | job counter [256] | 4 statistics slots |
 // slot chunks [7][256] x (4 ST) | slot observations [5][256] float4 | 4 wave-private job lists [256] u16
-constexpr int kManyLdsFixed = (kManyEnvs * RDV_OBS_DIM + kManyEnvs * RDV_ACT_DIM + 2 * kManyEnvs) * 4 + kManyEnvWaves * kStatWords * 8 +
+constexpr int kManyHandoverWords = 9;   // meta (stepped | fin << 1 | reason << 2), flags, k, and ep_ret, sum_dv, sum_dw as two words each
+constexpr int kManyLdsFixed = (kManyEnvs * RDV_OBS_DIM + kManyEnvs * kManyHandoverWords + 2 * kManyEnvs) * 4 + kManyEnvWaves * kStatWords * 8 +
                               kSlotObsVecs * kManyEnvs * 16 + kManyEnvWaves * kManyEnvs * 2;
-template <typename ST> constexpr int many_lds_bytes() { return kManyLdsFixed + kChunks * kManyEnvs * 4 * (int)sizeof(ST); }   // 77,312 / 105,984 B
+template <typename ST> constexpr int many_lds_bytes() { return kManyLdsFixed + kChunks * kManyEnvs * 4 * (int)sizeof(ST); }   // 80,384 / 109,056 B
 
 struct StepManyArgs {
   void* ws;                 // chunk arrays (state in, state out)
@@ -52,8 +55,9 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
   using V = typename Vec4<ST>::type;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* obs_rows = lds;                                                           // [256][17]
-  float* act_rows = obs_rows + kManyEnvs * RDV_OBS_DIM;                            // [256][6] (unused since the action rows are loaded straight into registers; kept in the layout)
-  uint32_t* job_kind = reinterpret_cast<uint32_t*>(act_rows + kManyEnvs * RDV_ACT_DIM);   // [256]
+  uint32_t* ho_words = reinterpret_cast<uint32_t*>(obs_rows + kManyEnvs * RDV_OBS_DIM);   // statistics hand-over: meta [256] | flags [256] | k [256] | 3 x double [256]
+  double* ho_reals = reinterpret_cast<double*>(ho_words + 3 * kManyEnvs + (kManyEnvs & 1));   // (8-byte aligned: 3 * 256 words)
+  uint32_t* job_kind = ho_words + kManyHandoverWords * kManyEnvs;                  // [256]
   uint32_t* job_counter = job_kind + kManyEnvs;                                    // [256]
   uint64_t* stat_lds = reinterpret_cast<uint64_t*>(job_counter + kManyEnvs);       // [4][16]
   V* slot_chunks = reinterpret_cast<V*>(stat_lds + kManyEnvWaves * kStatWords);   // [7][256]
@@ -127,11 +131,16 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
         if (A.done_reason)
           A.done_reason[o] = (uint8_t)(r.reason | ((fin && (e.flags & FLAG_COLLIDED)) ? 16 : 0) | ((fin && (e.flags >> SUCCESS_SHIFT) != 0u) ? 32 : 0));
       }
-      stats_update(my_stats, lane < 12 ? my_stats[lane] : 0ull, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
+      if (!resets) stats_update(my_stats, lane < 12 ? my_stats[lane] : 0ull, lane, stepped, fin, r.reason, e.flags, e.k, e.ep_ret, e.sum_dv, e.sum_dw);
       if (fin && A.on_done == RDV_ON_DONE_HALT) e.flags |= FLAG_HALTED;
       if (resets) {
         const bool take = fin;
-        __syncthreads();   // A: every slot listed earlier has been refilled
+        __syncthreads();   // A: every slot listed earlier has been refilled (and the previous step's hand-over has been read)
+        // the episode statistics of this step are the service wave's work: what stats_update reads of the episode that may end here
+        ho_words[slot] = (stepped ? 1u : 0u) | (fin ? 2u : 0u) | ((uint32_t)r.reason << 2);
+        ho_words[kManyEnvs + slot] = e.flags;
+        ho_words[2 * kManyEnvs + slot] = (uint32_t)e.k;
+        ho_reals[slot] = e.ep_ret; ho_reals[kManyEnvs + slot] = e.sum_dv; ho_reals[2 * kManyEnvs + slot] = e.sum_dw;
         if (take) {
           SlotRaw<ST> raw;
           slot_fetch<ST>(L, slot, raw);
@@ -167,13 +176,23 @@ __global__ __launch_bounds__(kManyBlock) void step_many_kernel(const DevParams* 
     // ------------------------------------------------------------------ service waves
     const int role = wv - kManyEnvWaves;
     uint16_t* list = lists + role * kManyEnvs;
+    uint64_t* stats_of = stat_lds + role * kStatWords;        // env wave `role`'s statistics slot (zeroed by it before S0)
+    // the statistics of the step whose hand-over lies in LDS (written between its barriers A and B), exactly as the env wave did them
+    auto statistics = [&]() {
+      const int sl = role * kWave + lane;
+      const uint32_t meta = ho_words[sl];
+      stats_update(stats_of, lane < 12 ? stats_of[lane] : 0ull, lane, (meta & 1u) != 0u, (meta & 2u) != 0u, (int)(meta >> 2), ho_words[kManyEnvs + sl],
+                   (int)ho_words[2 * kManyEnvs + sl], ho_reals[sl], ho_reals[kManyEnvs + sl], ho_reals[2 * kManyEnvs + sl]);
+    };
     __syncthreads();   // S0
     for (int k = 0; k < K; ++k) {
       refill_pass_lds<ST>(role, lane, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
+      if (k > 0) statistics();   // of step k - 1
       __syncthreads();   // A
       __syncthreads();   // B
     }
     refill_pass_lds<ST>(role, lane, P, L, job_kind, job_counter, list, block_base, n, A.seed, A.env_id_offset, A.tape, A.tape_depth);
+    if (K > 0) statistics();     // of the last step
     __syncthreads();   // F
   }
 }
