@@ -277,7 +277,9 @@ int rdv_get_aux(rdv_handle h, double* aux_out, void* stream);
  * evaluation or to branch rollouts from a common state.  `dst` / `src`: device buffers of rdv_snapshot_bytes(h) bytes, valid for
  * handles of the same n_envs and storage: a snapshot starts with a 64-byte header (magic, version, n_envs, storage, payload bytes)
  * that rdv_restore reads back and checks against the handle and against `src_bytes`, the size of the caller's buffer, before
- * anything is overwritten (this synchronises `stream`).  Parameters, seed and rigid bodies are not part of it. */
+ * anything is overwritten (this synchronises `stream`).  Parameters, seed and rigid bodies are not part of it.  The halted flags of
+ * a snapshot mean something to handles created with RDV_ON_DONE_HALT only: the step kernels of the other two modes never halt an env
+ * and do not test the flag (an env restored as halted steps on there). */
 int64_t rdv_snapshot_bytes(rdv_handle h);
 int rdv_snapshot(rdv_handle h, void* dst, void* stream);
 int rdv_restore(rdv_handle h, const void* src, int64_t src_bytes, void* stream);
