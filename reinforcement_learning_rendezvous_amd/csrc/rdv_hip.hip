@@ -322,7 +322,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
     // waves, and these 6 x 16-byte-per-lane stores drain inside that wait instead of after it (tools/lib_ab.py: 6.80 -> 6.73 us at
     // 65,536 envs, 5.35 -> 5.29 at 16,384; moving the reward / done / terminal-row stores there as well loses: 6.89).  Reset lanes: service wave.
     if (fin && A.on_done == RDV_ON_DONE_HALT) { e.flags |= FLAG_HALTED; if (kPack) packed[5].z = u2s(e.flags, ST(0)); }
-    if (stepped && !to_reset) { if (kPack) store_chunks<ST>(ws, A.cs, i, packed, false); else store_env<ST>(ws, A.cs, i, e, false); }
+    if (stepped && !to_reset) { if (kPack) store_chunks<ST, true>(ws, A.cs, i, packed, false); else store_env<ST>(ws, A.cs, i, e, false); }
     RDV_STAMP(3);
     __syncthreads();
     RDV_STAMP(4);
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(kSplitBlock) void step_kernel_split(void* ws_hot, c
         float robs[RDV_OBS_DIM];
         canon_rest<ST>(ne);
         observation(P, ne, robs);
-        store_env<ST>(ws, A.cs, i, ne, true);
+        store_env<ST, true>(ws, A.cs, i, ne, true);
 #pragma unroll
         for (int j = 0; j < RDV_OBS_DIM; ++j) wl[lane * RDV_OBS_DIM + j] = robs[j];
       }

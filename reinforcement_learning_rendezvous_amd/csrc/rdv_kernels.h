@@ -93,18 +93,33 @@ __device__ __forceinline__ void pack_env(const Env& e, typename Vec4<ST>::type* 
   c[5].x = (ST)e.ep_ret; c[5].y = u2s((uint32_t)e.k, t); c[5].z = u2s(e.flags, t); c[5].w = u2s(e.episode, t);
   c[6].x = (ST)e.wt[0]; c[6].y = (ST)e.wt[1]; c[6].z = (ST)e.wt[2]; c[6].w = ST(0);
 }
-template <typename ST>
+// kNt: non-temporal stores (fp32 storage).  For the split kernel's one workgroup per CU they shorten the launch boundary a little — less
+// is left dirty in L2 when the kernel ends — and the next launch still finds the lines in its XCD's L2 (tools/ubench_l2_retention.hip:
+// 3.19 -> 3.09 us per bare read-modify-write launch, 700 cycles to data either way; rdv_step 6.43 -> 6.38 us at 65,536 envs).  NOT for the
+// fused kernels of larger batches: 15.9 -> 20.3 us at 262,144 envs, 31.4 -> 44.6 at 524,288 (profiles/r04_input_latency.txt).
+template <typename ST, bool kNt = false>
 __device__ __forceinline__ void store_chunks(typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i,
                                              const typename Vec4<ST>::type* c, bool with_wt) {
+  if constexpr (kNt && sizeof(ST) == 4) {
+    typedef float st_f4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-  for (int k = 0; k < 6; ++k) ws[k * cs + i] = c[k];
-  if (with_wt) ws[6 * cs + i] = c[6];
+    for (int k = 0; k < 7; ++k) {
+      if (k < 6 || with_wt) {
+        const st_f4 v = {c[k].x, c[k].y, c[k].z, c[k].w};
+        __builtin_nontemporal_store(v, reinterpret_cast<st_f4*>(ws + k * cs + i));
+      }
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) ws[k * cs + i] = c[k];
+    if (with_wt) ws[6 * cs + i] = c[6];
+  }
 }
-template <typename ST>
+template <typename ST, bool kNt = false>
 __device__ __forceinline__ void store_env(typename Vec4<ST>::type* __restrict__ ws, int64_t cs, int64_t i, const Env& e, bool with_wt) {
   typename Vec4<ST>::type c[7];
   pack_env<ST>(e, c);
-  store_chunks<ST>(ws, cs, i, c, with_wt);
+  store_chunks<ST, kNt>(ws, cs, i, c, with_wt);
 }
 
 // Diagnostic build only (-DRDV_STAMPS, tools/stamp_profile.py): s_memtime stamps at the phase boundaries of the split
