@@ -119,7 +119,9 @@ def test_step_layouts_and_persistent_kernels_agree(case):
 def test_training_kernels_vs_oracle_with_philox_resets(storage, variant):
     """The training kernels themselves (no diagnostics) against the CPU oracle: config-2 shape, shortened; plus parameters
     that reset often."""
-    for n, T, kw in ((4096, 128, {}), (1500, 64, dict(t_max=5.0)), (700, 24, dict(t_max=1.0))):
+    # (the tiny batches: one env, one lane short of a wave, one lane into the second wave — the kernels' clamped input fetch and ragged tails)
+    for n, T, kw in ((4096, 128, {}), (1500, 64, dict(t_max=5.0)), (700, 24, dict(t_max=1.0)), (1, 40, dict(t_max=3.0)), (63, 24, dict(t_max=2.0)),
+                     (65, 24, dict(t_max=2.0))):
         p = make_params(**kw)
         env = _batch(n, params=p, storage=storage, seed=0, variant=variant)
         orc = oracle.OracleBatch(n, to_oracle_params(p), seed=0, n_threads=8,
