@@ -65,7 +65,7 @@ __global__ __launch_bounds__(kBlock) void step_kernel(void* ws_hot, const float*
     }
   }
   wave_lds_fence();
-  if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see kStreamRowsMaxEnvs
+  if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see StepArgs::stream_rows
   else store_obs_rows<false>(A.obs, wave_base, rows, lane, wl);
   // state write-back: 6 x 16-byte-per-lane stores (7 where a reset rewrote wt, or always when wt evolves)
   if (stepped) store_env<ST>(ws, A.cs, i, e, did_reset || kGeneral);

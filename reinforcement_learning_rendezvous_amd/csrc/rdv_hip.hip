@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(S
     wave_lds_fence();
   }
   RDV_STAMP(6);
-  if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see kStreamRowsMaxEnvs
+  if (A.stream_rows) store_obs_rows<true>(A.obs, wave_base, rows, lane, wl);   // kernel-uniform: see StepArgs::stream_rows
   else store_obs_rows<false>(A.obs, wave_base, rows, lane, wl);
   RDV_STAMP(7);
   RDV_STAMP_FLUSH((uint64_t)blockIdx.x * (kBlock / kWave) + wave_in_block)
@@ -1256,7 +1256,8 @@ int rdv_step(rdv_handle h, const float* actions, const RdvStepOut* out, void* st
     else { if (all) RDV_LAUNCH((step_kernel_split<double, true>), grid, block); else RDV_LAUNCH((step_kernel_split<double, false>), grid, block); }
   } else {
     dim3 grid = grid_for(h->n), block(kBlock);
-    A.stream_rows = h->n <= kStreamRowsMaxEnvs ? 1 : 0;
+    { static const int forced = [] { const char* x = getenv("RDV_STREAM_ROWS"); return x ? atoi(x) : -1; }();   // diagnostics
+      A.stream_rows = forced >= 0 ? (forced ? 1 : 0) : 1; }
     { static const int forced = [] { const char* x = getenv("RDV_STAGGER"); return x ? atoi(x) : -1; }();     // diagnostics: units of 512 cycles
       A.stagger = forced >= 0 ? forced : stagger_by_size(h->n); }
     if (h->xcd_order == 1 || (h->xcd_order < 0 && xcd_order_by_size(h->n))) {

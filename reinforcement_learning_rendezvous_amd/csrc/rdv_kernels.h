@@ -29,10 +29,13 @@ constexpr int kStatWords = 16;          // 128-byte slot per wave
 // environment at rdv_create forces it off / on (diagnostics).
 constexpr int64_t kXcdOrderMaxEnvs = 3145728;
 static inline bool xcd_order_by_size(int64_t n) { return n <= kXcdOrderMaxEnvs && n % 65536 == 0; }
-// Fused kernel: the observation rows leave with non-temporal stores up to this size (tools/lib_ab.py, same box, alternating child
-// processes, us per launch plain -> streamed): 98,304 envs 11.02 -> 10.69, 131,072 11.48 -> 11.19, 196,608 14.8 -> 13.6, 262,144
-// 22.57 -> 21.24, 327,680 26.98 -> 26.57, 393,216 30.9 -> 30.1; 458,752 and 524,288 +-2 % either way, 786,432 57.7 -> 61.6 (worse).
-constexpr int64_t kStreamRowsMaxEnvs = 393216;
+// Fused kernels: the observation rows leave with non-temporal stores at EVERY size (round 4; tools/lib_ab_large.py, alternating child
+// processes, six fresh allocations each, us per launch plain -> streamed): 524,288 envs 31.35 -> 31.05, 786,432 46.2 -> 45.3, 1,048,576
+// 73 -> 59, 2,097,152 175.7 -> 143, 4,194,304 279-338 -> 260-306 (profiles/r04_stream_rows.txt).  Rounds 2-3 had streamed them up to
+// 393,216 envs only (plain -> streamed then: 98,304 envs 11.02 -> 10.69, 262,144 22.57 -> 21.24, 393,216 30.9 -> 30.1, 786,432 57.7 ->
+// 61.6: worse with the kernel of that round).  The rows are written once and not read by these kernels; the state, which the next launch
+// reads back, must NOT be streamed at these sizes (31.4 -> 44.6 us at 524,288 envs).  RDV_STREAM_ROWS=0|1 in the environment at rdv_step
+// forces it (diagnostics).
 constexpr int kTilesPerCU = 3;                  // RDV_VARIANT_FUSED_TILES: workgroups per CU (three waves per SIMD at <= 168 registers)
 // step_kernel_parts: start-up stagger of the first-round workgroups in units of 512 cycles per CU slot, by batch size (tools/lib_ab_large.py on one
 // box, alternating processes, us per launch without | with; profiles/r04_stagger.txt): 196,608 envs 12.9 | 13.3 (6 units: worse), 262,144 17.5 | 16.4 (6),
@@ -166,7 +169,7 @@ struct StepArgs {
   void* prep;               // prepared next-episode states of the persistent kernels (csrc/rdv_slots.h): one record per env
   uint32_t* prep_tag;       // [N]
   int32_t xcd_per;          // fused kernels: workgroups per XCD region (0: plain block order)
-  int32_t stream_rows;      // fused kernels: store the observation rows non-temporally (kStreamRowsMaxEnvs)
+  int32_t stream_rows;      // fused kernels: store the observation rows non-temporally (rdv_kernels.h: at every size since round 4)
   int32_t stagger;          // step_kernel_parts: first-round workgroups start k x 2,048 cycles apart by their slot on the CU (0: off)
 #ifdef RDV_STAMPS
   unsigned long long* stamps;
