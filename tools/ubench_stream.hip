@@ -35,6 +35,32 @@ __global__ __launch_bounds__(256) void k_soa(const float4* __restrict__ in, floa
   if ((threadIdx.x & 63) < 16) obs[wave_base * 17 / 4 + 256 + (threadIdx.x & 63)] = c[6];
 }
 
+// k_soa with the observation rows written by non-temporal stores (round 4: the product streams them at every size)
+typedef float us_f4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_soa_ntrows(const float4* __restrict__ in, float4* __restrict__ out, const float2* __restrict__ act,
+                                                     float4* __restrict__ obs, long n, int work) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float4 c[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) c[k] = in[k * n + i];
+  const long wave_base = i - (threadIdx.x & 63);
+  float2 a[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) a[q] = act[wave_base * 3 + q * 64 + (threadIdx.x & 63)];
+  float s = a[0].x + a[1].y + a[2].x;
+  for (int w = 0; w < work; ++w) {
+#pragma unroll
+    for (int k = 0; k < 7; ++k) c[k].x = __builtin_fmaf(c[k].x, 1.0000001f, s);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) out[k * n + i] = c[k];
+  us_f4* o = reinterpret_cast<us_f4*>(obs);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const us_f4 v = {c[k].x, c[k].y, c[k].z, c[k].w}; __builtin_nontemporal_store(v, o + wave_base * 17 / 4 + k * 64 + (threadIdx.x & 63)); }
+  if ((threadIdx.x & 63) < 16) { const us_f4 v = {c[6].x, c[6].y, c[6].z, c[6].w}; __builtin_nontemporal_store(v, o + wave_base * 17 / 4 + 256 + (threadIdx.x & 63)); }
+}
+
 // the soa stream with an fp64 chain (7 x work dependent v_fma_f64 per lane): the arithmetic class of the product's transition
 __global__ __launch_bounds__(256) void k_soa64(const float4* __restrict__ in, float4* __restrict__ out, const float2* __restrict__ act,
                                                 float4* __restrict__ obs, long n, int work) {
@@ -127,6 +153,35 @@ static void boundary_floor(long n, const float4* in, float4* out, const float2* 
 
 int main(int argc, char** argv) {
   const long n = argc > 1 ? atol(argv[1]) : 4194304;
+  if (argc > 2 && argv[2][0] == 'r') {
+    // "rows": the bare pattern in place (in == out), observation rows plain against non-temporal, four fresh allocations, median of 7 timings of 4 launches
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    for (int trial = 0; trial < 4; ++trial) {
+      float4 *st, *obs; float2* act;
+      CHECK(hipMalloc(&st, n * 7 * 16)); CHECK(hipMalloc(&obs, n * 17 * 4 + 4096)); CHECK(hipMalloc(&act, n * 24));
+      CHECK(hipMemset(st, 0, n * 7 * 16)); CHECK(hipMemset(act, 0, n * 24));
+      float med[2];
+      for (int which = 0; which < 2; ++which) {
+        float t[7];
+        for (int rep = 0; rep < 9; ++rep) {
+          CHECK(hipEventRecord(e0));
+          for (int it = 0; it < 4; ++it) {
+            if (which == 0) hipLaunchKernelGGL(k_soa, grid, block, 0, 0, (const float4*)st, st, act, obs, n, 100);
+            else hipLaunchKernelGGL(k_soa_ntrows, grid, block, 0, 0, (const float4*)st, st, act, obs, n, 100);
+          }
+          CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+          float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+          if (rep >= 2) t[rep - 2] = ms / 4;
+        }
+        for (int a = 0; a < 7; ++a) for (int b = a + 1; b < 7; ++b) if (t[b] < t[a]) { float x = t[a]; t[a] = t[b]; t[b] = x; }
+        med[which] = t[3];
+      }
+      printf("allocation %d: bare pattern in place, rows plain %7.1f us   rows non-temporal %7.1f us   (n=%ld, 700 fp32 fma per lane)\n", trial, med[0] * 1e3, med[1] * 1e3, n);
+      CHECK(hipFree(st)); CHECK(hipFree(obs)); CHECK(hipFree(act));
+    }
+    return 0;
+  }
   if (argc > 2 && argv[2][0] == 'm') {
     // "modes": fresh allocations, the state updated IN PLACE as the product does (in == out), soa against aos, median of 7 timings of 4 launches
     // each — does the launch time of the bare access pattern depend on the allocation, and does one contiguous state stream per wave (aos) behave better?
