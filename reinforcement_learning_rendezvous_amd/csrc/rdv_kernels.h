@@ -41,7 +41,9 @@ constexpr int kTilesPerCU = 3;                  // RDV_VARIANT_FUSED_TILES: work
 // box, alternating processes, us per launch without | with; profiles/r04_stagger.txt): 196,608 envs 12.9 | 13.3 (6 units: worse), 262,144 17.5 | 16.4 (6),
 // 393,216 26.9 | 24.8 (8), 524,288 33.8 | 31.1 (8), 786,432 and 1,048,576: within the noise (4), 4,194,304: none at any value — sixteen rounds fall out of
 // step by themselves.  On between 229,376 and 655,360 envs (one to two and a half rounds of four workgroups per CU).
-static inline int stagger_by_size(int64_t n) { return (n < 229376 || n >= 655360) ? 0 : n < 393216 ? 6 : 8; }
+// Round 4, late (rows streamed, inputs pinned): 8 units also help a little at 655,360 (38.8 -> 37.8), 786,432 (45.3 -> 44.4) and 1,048,576 envs (60 -> 57.9);
+// 1.5 M and 2 M: within the spread of the allocations — the upper end moved from 655,360 to 1,310,720 envs.
+static inline int stagger_by_size(int64_t n) { return (n < 229376 || n >= 1310720) ? 0 : n < 393216 ? 6 : 8; }
 constexpr int64_t kSplitAutoMaxEnvs = 65536;    // measured crossover (tools/n_sweep.py, profiles/r02_n_sweep_parts.csv): split wins up to one 256-env workgroup per CU
 enum { ST_STEPS = 0, ST_EPISODES, ST_SUCCESS, ST_COLLIDED, ST_REASON0, ST_REASON1, ST_REASON2, ST_REASON3,
        ST_SUM_LEN, ST_SUM_RET, ST_SUM_DV, ST_SUM_DW };
