@@ -267,12 +267,14 @@ __device__ __forceinline__ double readlane_f64(double v, int src_lane) {
 // totals upwards; lane 63 ends with the sum of all 64 lanes.  A fixed tree: the fp64 sums are reproducible run to run and the same
 // in every kernel (they all reduce through here).  Round 1 walked the finished lanes with v_readlane in a scalar loop — serial,
 // ~0.7 us of the step wave at 65,536 envs (ablation: profiles/r02_ablation_split.txt).
+// (a step over all four rows asks the hardware for the zero of a lane without a source — bound_ctrl — instead of presetting the
+//  destination: two v_mov less per fp64 step, the same values; the row_bcast steps write two rows only and keep the preset zero)
 template <int kCtrl, int kRowMask>
-__device__ __forceinline__ int dpp_shift_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xf, false); }
+__device__ __forceinline__ int dpp_shift_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, kCtrl, kRowMask, 0xf, kRowMask == 0xf); }
 template <int kCtrl, int kRowMask>
 __device__ __forceinline__ double dpp_step_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, 0xf, kRowMask == 0xf);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, 0xf, kRowMask == 0xf);
   return v + __hiloint2double(hi, lo);      // lanes outside the row mask / without a source lane add +0.0
 }
 __device__ __forceinline__ double wave_sum_f64(double v) {
